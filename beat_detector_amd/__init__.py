@@ -1,0 +1,31 @@
+"""MI355X-native implementation of beat-detector's per-window analysis path.
+
+Python mirror of the reference's public interface for this path
+(`StrategyKind`, `Strategy::is_beat`, `BeatInfo`; src/lib.rs:51-185 of the
+reference) over the C ABI declared in ``include/beat_detector_hip.h``, plus the
+batched entry points.  All computation happens in ``libbeatdet_hip.so`` on the
+GPU; there is no CPU implementation in this package and every compute call
+fails loudly when the library or a GPU is missing.
+"""
+from .api import (  # noqa: F401
+    BeatInfo,
+    BeatDetectorError,
+    Params,
+    Strategy,
+    StrategyKind,
+    analyze_batch,
+    analyze_batch_host,
+    analyze_batch_multi,
+    batch_callbacks,
+    batch_candidates,
+    batch_max_beats,
+    device_count,
+    f32_data_to_i16,
+    last_kernel_name,
+    lib,
+    lib_path,
+    refractory,
+    synth_fill,
+    synth_fill_host,
+    u16_data_to_i16,
+)

@@ -1,0 +1,425 @@
+"""ctypes binding of libbeatdet_hip.so and the Python mirror of the reference's
+per-window interface (src/lib.rs:51-185 of the reference).
+
+torch is only plumbing here: device memory (tensors whose ``data_ptr()`` is
+handed to the library) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+try:  # torch must be loaded first so that both share one HIP runtime
+    import torch
+except Exception:  # pragma: no cover - torch is present in the target image
+    torch = None
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libbeatdet_hip.so"
+
+BD_OK = 0
+BD_ERR_INVALID_ARG = -1
+BD_ERR_NO_DEVICE = -2
+BD_ERR_HIP = -3
+BD_ERR_UNSUPPORTED = -4
+BD_ERR_EMPTY_WINDOW = -5
+BD_ERR_NO_BINS = -6
+BD_ERR_STOPPED = -7
+
+BD_DIV_BINS, BD_DIV_FFT_LEN, BD_DIV_NONE = 0, 1, 2
+
+
+class BeatDetectorError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"beat_detector_amd: status {status}: {message}")
+        self.status = status
+
+
+class Params(C.Structure):
+    """bd_params of include/beat_detector_hip.h."""
+
+    _fields_ = [
+        ("min_amplitude", C.c_uint32),
+        ("min_beat_gap_ms", C.c_uint32),
+        ("spectrum_max_hz", C.c_float),
+        ("spectrum_threshold", C.c_float),
+        ("spectrum_divisor", C.c_uint32),
+        ("spectrum_include_dc", C.c_uint32),
+        ("spectrum_inclusive", C.c_uint32),
+        ("spectrum_dc_packs_nyquist", C.c_uint32),
+        ("lpf_cutoff_hz", C.c_uint32),
+        ("lpf_ratio", C.c_float),
+    ]
+
+    @classmethod
+    def default(cls, **overrides) -> "Params":
+        p = cls()
+        lib().bd_default_params(C.byref(p))
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def lib() -> C.CDLL:
+    """Loads libbeatdet_hip.so (built in-tree by `__graft_entry__.build()` or
+    `make -C beat_detector_amd/csrc`).  No fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise BeatDetectorError(BD_ERR_HIP, f"{path} is missing: build it with `make -C beat_detector_amd/csrc`")
+    L = C.CDLL(path)
+    u32, u64, i32, vp, f32 = C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_float
+    pp = C.POINTER(Params)
+    sigs = {
+        "bd_default_params": (None, [pp]),
+        "bd_strerror": (C.c_char_p, [i32]),
+        "bd_last_error": (C.c_char_p, []),
+        "bd_device_count": (i32, [C.POINTER(i32)]),
+        "bd_kind_count": (i32, []),
+        "bd_kind_name": (C.c_char_p, [i32]),
+        "bd_kind_description": (C.c_char_p, [i32]),
+        "bd_kind_min_duration_between_beats_ms": (u32, [i32]),
+        "bd_detector_create": (i32, [i32, u32, pp, i32, C.POINTER(vp)]),
+        "bd_detector_is_beat": (i32, [vp, vp, C.c_size_t, C.POINTER(u32)]),
+        "bd_detector_kind": (i32, [vp]),
+        "bd_detector_last": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
+        "bd_detector_destroy": (None, [vp]),
+        "bd_batch_callbacks": (u64, [u64, u32]),
+        "bd_batch_max_beats": (u32, [u32, u32, pp, u64, u32]),
+        "bd_analyze_batch": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, vp]),
+        "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp]),
+        "bd_analyze_batch_host": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, i32]),
+        "bd_analyze_batch_multi": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, C.POINTER(i32), i32]),
+        "bd_refractory": (i32, [u32, pp, u32, vp, u64, u64, vp, vp, vp, u32, vp]),
+        "bd_u16_data_to_i16": (i32, [vp, vp, u64, vp]),
+        "bd_f32_data_to_i16": (i32, [vp, vp, u64, vp]),
+        "bd_synth_fill": (i32, [vp, u64, u64, u64, u64, u64, u32, vp]),
+        "bd_synth_fill_host": (i32, [vp, u64, u64, u64, u64, u64, u32]),
+        "bd_last_kernel_name": (C.c_char_p, []),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "bd_default_params bd_strerror bd_last_error bd_device_count bd_kind_count bd_kind_name "
+    "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
+    "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
+    "bd_batch_max_beats bd_analyze_batch bd_batch_candidates bd_analyze_batch_host "
+    "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
+    "bd_synth_fill_host bd_last_kernel_name"
+).split()
+
+
+def _check(status: int) -> int:
+    if status < 0:
+        raise BeatDetectorError(status, lib().bd_last_error().decode() or lib().bd_strerror(status).decode())
+    return status
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(lib().bd_device_count(C.byref(n)))
+    return n.value
+
+
+def last_kernel_name() -> str:
+    return lib().bd_last_kernel_name().decode()
+
+
+# --------------------------------------------------------------------------
+# Reference interface mirror
+# --------------------------------------------------------------------------
+class BeatInfo:
+    """src/lib.rs:51-66."""
+
+    __slots__ = ("_relative_ms",)
+
+    def __init__(self, relative_ms: int):
+        self._relative_ms = int(relative_ms)
+
+    def relative_ms(self) -> int:
+        return self._relative_ms
+
+    def __repr__(self) -> str:
+        return f"BeatInfo {{ relative_ms: {self._relative_ms} }}"
+
+    def __eq__(self, other) -> bool:
+        return isinstance(other, BeatInfo) and other._relative_ms == self._relative_ms
+
+
+class StrategyKind(enum.Enum):
+    """src/lib.rs:142-185.  Values follow StrategyKind::values()."""
+
+    LPF = 0
+    Spectrum = 1
+
+    def detector(self, sampling_rate: int, params: Optional[Params] = None, device: int = -1) -> "Strategy":
+        """StrategyKind::detector, src/lib.rs:155-161."""
+        return Strategy(self, sampling_rate, params, device)
+
+    def name_(self) -> str:
+        """StrategyKind::name, src/lib.rs:164-170 (`name` is taken by Enum)."""
+        return lib().bd_kind_name(self.value).decode()
+
+    def description(self) -> str:
+        """StrategyKind::description, src/lib.rs:173-179."""
+        return lib().bd_kind_description(self.value).decode()
+
+    def min_duration_between_beats_ms(self) -> int:
+        return lib().bd_kind_min_duration_between_beats_ms(self.value)
+
+    @classmethod
+    def values(cls) -> List["StrategyKind"]:
+        """StrategyKind::values, src/lib.rs:182-184."""
+        return [cls.LPF, cls.Spectrum]
+
+
+class Strategy:
+    """A detector (`Box<dyn Strategy + Send>`, src/lib.rs:72-137) whose state and
+    arithmetic live on the GPU.  One thread at a time per object."""
+
+    def __init__(self, kind: StrategyKind, sampling_rate: int, params: Optional[Params] = None, device: int = -1):
+        self._h = C.c_void_p()
+        self._kind = kind
+        _check(lib().bd_detector_create(kind.value, sampling_rate, C.byref(params) if params is not None else None,
+                                        device, C.byref(self._h)))
+
+    def is_beat(self, samples) -> Optional[BeatInfo]:
+        """Strategy::is_beat(&self, samples: &[i16]) -> Option<BeatInfo>, src/lib.rs:78."""
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        ms = C.c_uint32(0)
+        r = _check(lib().bd_detector_is_beat(self._h, a.ctypes.data_as(C.c_void_p), a.size, C.byref(ms)))
+        return BeatInfo(ms.value) if r == 1 else None
+
+    def kind(self) -> StrategyKind:
+        return StrategyKind(_check(lib().bd_detector_kind(self._h)))
+
+    def last(self):
+        """(analysed value, decision before the refractory rule) of the last call."""
+        v, c = C.c_float(0), C.c_int(0)
+        _check(lib().bd_detector_last(self._h, C.byref(v), C.byref(c)))
+        return v.value, bool(c.value)
+
+    def close(self) -> None:
+        if self._h:
+            lib().bd_detector_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------
+# Batched entry points
+# --------------------------------------------------------------------------
+def batch_callbacks(n_samples: int, callback_len: int) -> int:
+    return lib().bd_batch_callbacks(n_samples, callback_len)
+
+
+def batch_max_beats(kind: StrategyKind, sampling_rate: int, n_samples: int, callback_len: int,
+                    params: Optional[Params] = None) -> int:
+    return lib().bd_batch_max_beats(kind.value, sampling_rate, C.byref(params) if params is not None else None,
+                                    n_samples, callback_len)
+
+
+def _stream_ptr(stream) -> Optional[int]:
+    if stream is None:
+        if torch is not None and torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+        return None
+    return getattr(stream, "cuda_stream", stream)
+
+
+def _pp(params):
+    return C.byref(params) if params is not None else None
+
+
+def _dev_ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(t, dtype, name):
+    if torch is None:
+        raise BeatDetectorError(BD_ERR_NO_DEVICE, "torch is required for device tensors")
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, f"{name} must be a contiguous CUDA tensor of {dtype}")
+
+
+def batch_candidates(kind: StrategyKind, sampling_rate: int, samples, callback_len: int,
+                     n_samples: Optional[int] = None, params: Optional[Params] = None,
+                     want_values: bool = True, values=None, flags=None, stream=None):
+    """First stage only: per-callback value and decision.  `samples` is a CUDA
+    int16 tensor [n_streams, stride]."""
+    _require_cuda(samples, torch.int16, "samples")
+    n_streams, stride = samples.shape
+    n = stride if n_samples is None else n_samples
+    n_cb = n // callback_len if callback_len else 0
+    if flags is None:
+        flags = torch.empty((n_streams, n_cb), dtype=torch.uint8, device=samples.device)
+    if values is None and want_values:
+        values = torch.empty((n_streams, n_cb), dtype=torch.float32, device=samples.device)
+    with torch.cuda.device(samples.device):
+        _check(lib().bd_batch_candidates(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams, n,
+                                         stride, callback_len, _dev_ptr(values), flags.data_ptr(),
+                                         _stream_ptr(stream)))
+    return values, flags
+
+
+def refractory(sampling_rate: int, callback_len: int, flags, max_beats: int, params: Optional[Params] = None,
+               stream=None):
+    _require_cuda(flags, torch.uint8, "flags")
+    n_streams, n_cb = flags.shape
+    dev = flags.device
+    count = torch.empty((n_streams,), dtype=torch.int32, device=dev)
+    idx = torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev)
+    ms = torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _check(lib().bd_refractory(sampling_rate, _pp(params), callback_len, flags.data_ptr(), n_streams, n_cb,
+                                   count.data_ptr(), idx.data_ptr(), ms.data_ptr(), max_beats, _stream_ptr(stream)))
+    return count, idx, ms
+
+
+class BatchResult:
+    __slots__ = ("values", "flags", "beat_count", "beat_idx", "beat_ms")
+
+    def __init__(self, values, flags, beat_count, beat_idx, beat_ms):
+        self.values, self.flags = values, flags
+        self.beat_count, self.beat_idx, self.beat_ms = beat_count, beat_idx, beat_ms
+
+    def beats(self, stream_index: int):
+        """[(callback index, relative_ms)] of one stream (host lists)."""
+        n = int(self.beat_count[stream_index])
+        n = min(n, self.beat_idx.shape[1])
+        idx = np.asarray(self.beat_idx[stream_index][:n].cpu() if hasattr(self.beat_idx, "cpu") else self.beat_idx[stream_index][:n])
+        ms = np.asarray(self.beat_ms[stream_index][:n].cpu() if hasattr(self.beat_ms, "cpu") else self.beat_ms[stream_index][:n])
+        return list(zip(idx.astype(np.int64).tolist(), ms.astype(np.int64).tolist()))
+
+
+def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len: int,
+                  n_samples: Optional[int] = None, params: Optional[Params] = None,
+                  max_beats: Optional[int] = None, want_values: bool = True, out: Optional[BatchResult] = None,
+                  stream=None) -> BatchResult:
+    """bd_analyze_batch on a CUDA int16 tensor [n_streams, stride].  Enqueues on
+    the current torch stream; results are CUDA tensors."""
+    _require_cuda(samples, torch.int16, "samples")
+    n_streams, stride = samples.shape
+    n = stride if n_samples is None else n_samples
+    n_cb = n // callback_len if callback_len else 0
+    dev = samples.device
+    if max_beats is None:
+        max_beats = max(1, batch_max_beats(kind, sampling_rate, n, callback_len, params)) if callback_len else 1
+    if out is None:
+        out = BatchResult(
+            torch.empty((n_streams, n_cb), dtype=torch.float32, device=dev) if want_values else None,
+            torch.empty((n_streams, n_cb), dtype=torch.uint8, device=dev),
+            torch.zeros((n_streams,), dtype=torch.int32, device=dev),
+            torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
+            torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
+        )
+    with torch.cuda.device(dev):
+        _check(lib().bd_analyze_batch(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams, n, stride,
+                                      callback_len, _dev_ptr(out.values), out.flags.data_ptr(),
+                                      out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
+                                      out.beat_idx.shape[1], _stream_ptr(stream)))
+    return out
+
+
+def _host_call(fn_name, kind, sampling_rate, samples, callback_len, params, max_beats, tail):
+    a = np.ascontiguousarray(samples, dtype=np.int16)
+    if a.ndim == 1:
+        a = a[None, :]
+    n_streams, n = a.shape
+    n_cb = n // callback_len if callback_len else 0
+    if max_beats is None:
+        max_beats = max(1, batch_max_beats(kind, sampling_rate, n, callback_len, params)) if callback_len else 1
+    values = np.zeros((n_streams, n_cb), dtype=np.float32)
+    flags = np.zeros((n_streams, n_cb), dtype=np.uint8)
+    count = np.zeros((n_streams,), dtype=np.uint32)
+    idx = np.zeros((n_streams, max_beats), dtype=np.uint32)
+    ms = np.zeros((n_streams, max_beats), dtype=np.uint32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    _check(getattr(lib(), fn_name)(kind.value, sampling_rate, _pp(params), vp(a), n_streams, n, n, callback_len,
+                                   vp(values), vp(flags), vp(count), vp(idx), vp(ms), max_beats, *tail))
+    return BatchResult(values, flags, count, idx, ms)
+
+
+def analyze_batch_host(kind: StrategyKind, sampling_rate: int, samples, callback_len: int,
+                       params: Optional[Params] = None, max_beats: Optional[int] = None,
+                       device: int = -1) -> BatchResult:
+    """bd_analyze_batch_host on a numpy int16 array [n_streams, n_samples]."""
+    return _host_call("bd_analyze_batch_host", kind, sampling_rate, samples, callback_len, params, max_beats, (device,))
+
+
+def analyze_batch_multi(kind: StrategyKind, sampling_rate: int, samples, callback_len: int,
+                        devices: Sequence[int], params: Optional[Params] = None,
+                        max_beats: Optional[int] = None) -> BatchResult:
+    """bd_analyze_batch_multi: contiguous stream shards over `devices`."""
+    arr = (C.c_int * len(devices))(*devices)
+    return _host_call("bd_analyze_batch_multi", kind, sampling_rate, samples, callback_len, params, max_beats,
+                      (arr, len(devices)))
+
+
+# --------------------------------------------------------------------------
+# Ingest converters and the synthetic generator
+# --------------------------------------------------------------------------
+def u16_data_to_i16(data, stream=None):
+    """record::u16_data_to_i16, src/record.rs:151-158, on a CUDA tensor.  torch
+    has no uint16 arithmetic, so the input is an int16 tensor holding the u16 bits."""
+    _require_cuda(data, torch.int16, "data")
+    out = torch.empty_like(data)
+    with torch.cuda.device(data.device):
+        _check(lib().bd_u16_data_to_i16(data.data_ptr(), out.data_ptr(), data.numel(), _stream_ptr(stream)))
+    return out
+
+
+def f32_data_to_i16(data, stream=None):
+    """record::f32_data_to_i16, src/record.rs:160-166, on a CUDA tensor."""
+    _require_cuda(data, torch.float32, "data")
+    out = torch.empty(data.shape, dtype=torch.int16, device=data.device)
+    with torch.cuda.device(data.device):
+        _check(lib().bd_f32_data_to_i16(data.data_ptr(), out.data_ptr(), data.numel(), _stream_ptr(stream)))
+    return out
+
+
+def synth_fill(samples, n_samples: Optional[int] = None, first_stream: int = 0, seed: int = 0x5EED,
+               sampling_rate: int = 44100, stream=None):
+    """Fills a CUDA int16 tensor [n_streams, stride] with synthetic click tracks."""
+    _require_cuda(samples, torch.int16, "samples")
+    n_streams, stride = samples.shape
+    n = stride if n_samples is None else n_samples
+    with torch.cuda.device(samples.device):
+        _check(lib().bd_synth_fill(samples.data_ptr(), n_streams, n, stride, first_stream, seed, sampling_rate,
+                                   _stream_ptr(stream)))
+    return samples
+
+
+def synth_fill_host(n_streams: int, n_samples: int, first_stream: int = 0, seed: int = 0x5EED,
+                    sampling_rate: int = 44100) -> np.ndarray:
+    """The same generator on the host (integer arithmetic only, bit-identical)."""
+    out = np.zeros((n_streams, n_samples), dtype=np.int16)
+    _check(lib().bd_synth_fill_host(out.ctypes.data_as(C.c_void_p), n_streams, n_samples, n_samples, first_stream,
+                                    seed, sampling_rate))
+    return out

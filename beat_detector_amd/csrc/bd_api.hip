@@ -1,0 +1,383 @@
+// C-ABI glue: parameters, strategy metadata, error reporting and the batched
+// entry points (device pointers, host pointers, stream-sharded multi-GPU).
+#include "bd_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+// ---- errors -------------------------------------------------------------------
+static thread_local char bd_err_buf[512] = "";
+static thread_local const char *bd_last_kernel = "";
+
+void bd_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(bd_err_buf, sizeof(bd_err_buf), fmt, ap);
+    va_end(ap);
+}
+
+void bd_set_last_kernel(const char *name) { bd_last_kernel = name; }
+
+int bd_check_hip(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return BD_OK;
+    bd_set_error("%s: %s", what, hipGetErrorString(e));
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return BD_ERR_NO_DEVICE;
+    return BD_ERR_HIP;
+}
+
+extern "C" const char *bd_last_error(void) { return bd_err_buf; }
+extern "C" const char *bd_last_kernel_name(void) { return bd_last_kernel; }
+
+extern "C" const char *bd_strerror(int status)
+{
+    switch (status) {
+    case BD_OK: return "ok";
+    case BD_ERR_INVALID_ARG: return "invalid argument";
+    case BD_ERR_NO_DEVICE: return "no usable GPU";
+    case BD_ERR_HIP: return "HIP runtime error";
+    case BD_ERR_UNSUPPORTED: return "unsupported size or configuration";
+    case BD_ERR_EMPTY_WINDOW: return "empty sample window";
+    case BD_ERR_NO_BINS: return "no spectrum bin inside the frequency limit";
+    case BD_ERR_STOPPED: return "keep_recording is false";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int bd_device_count(int *count)
+{
+    if (!count) return BD_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return BD_OK;
+}
+
+// ---- parameters and plan ----------------------------------------------------------
+extern "C" void bd_default_params(bd_params *p)
+{
+    if (!p) return;
+    p->min_amplitude = 9830;           // (i16::MAX as f32 * 0.3) as i16, src/lib.rs:134
+    p->min_beat_gap_ms = 400;          // spectrum.rs:130, lpf.rs:113
+    p->spectrum_max_hz = 90.0f;        // spectrum.rs:85
+    p->spectrum_threshold = 2100000.0f;// spectrum.rs:92
+    p->spectrum_divisor = BD_DIV_BINS;
+    p->spectrum_include_dc = 1;
+    p->spectrum_inclusive = 1;
+    p->spectrum_dc_packs_nyquist = 0;
+    p->lpf_cutoff_hz = 120;            // lpf.rs:65
+    p->lpf_ratio = 0.77f;              // lpf.rs:74
+}
+
+int bd_make_plan(int kind, uint32_t sampling_rate, const bd_params *params, bd_plan *plan)
+{
+    if (kind != BD_KIND_LPF && kind != BD_KIND_SPECTRUM) {
+        bd_set_error("unknown strategy kind %d", kind);
+        return BD_ERR_INVALID_ARG;
+    }
+    if (sampling_rate == 0) { bd_set_error("sampling rate must be positive"); return BD_ERR_INVALID_ARG; }
+    bd_params p;
+    if (params) p = *params; else bd_default_params(&p);
+    memset(plan, 0, sizeof(*plan));
+    plan->kind = kind;
+    plan->sampling_rate = sampling_rate;
+    plan->ms_per_sample = 1.0f / (float)sampling_rate * 1000.0f; // mod.rs:64
+    plan->min_amp = p.min_amplitude;
+    plan->gap_ms = p.min_beat_gap_ms;
+    plan->threshold = p.spectrum_threshold;
+    plan->dc_packs_nyquist = p.spectrum_dc_packs_nyquist ? 1u : 0u;
+    plan->lpf_ratio = p.lpf_ratio;
+    if (kind == BD_KIND_SPECTRUM) {
+        // bins 0..N/2 at k * (fs as f32 / N as f32), kept while inside the limit
+        const float res = (float)sampling_rate / (float)BD_RING_LEN;
+        int last = -1;
+        for (int k = 0; k <= BD_RING_LEN / 2; k++) {
+            const float fr = (float)k * res;
+            const bool keep = p.spectrum_inclusive ? (fr <= p.spectrum_max_hz) : (fr < p.spectrum_max_hz);
+            if (keep) last = k; else break;
+        }
+        plan->first_bin = p.spectrum_include_dc ? 0 : 1;
+        plan->last_bin = last;
+        plan->n_bins = last - plan->first_bin + 1;
+        if (plan->n_bins <= 0 || !(p.spectrum_max_hz <= (float)sampling_rate / 2.0f)) {
+            bd_set_error("no spectrum bin within %.1f Hz at %u Hz sampling rate", p.spectrum_max_hz, sampling_rate);
+            return BD_ERR_NO_BINS;
+        }
+        switch (p.spectrum_divisor) {
+        case BD_DIV_BINS: plan->divisor = (float)plan->n_bins; break;
+        case BD_DIV_FFT_LEN: plan->divisor = (float)BD_RING_LEN; break;
+        case BD_DIV_NONE: plan->divisor = 0.0f; break;
+        default: bd_set_error("unknown spectrum_divisor %u", p.spectrum_divisor); return BD_ERR_INVALID_ARG;
+        }
+    } else {
+        // lowpass-filter: rc = 1/(fc*2*pi), dt = 1/fs, alpha = dt/(rc+dt); the
+        // reference passes the sampling rate `as u16` (lpf.rs:69)
+        const uint16_t sr16 = (uint16_t)sampling_rate;
+        const uint16_t fc16 = (uint16_t)p.lpf_cutoff_hz;
+        const float pi = 3.14159265358979323846f;
+        const float rc = 1.0f / ((float)fc16 * 2.0f * pi);
+        const float dt = 1.0f / (float)sr16;
+        const float alpha = dt / (rc + dt);
+        plan->alpha = alpha;
+        plan->alpha_valid = (alpha == alpha) && alpha >= 0.0f && alpha <= 1.0f;
+    }
+    return BD_OK;
+}
+
+void bd_clock_step(const bd_plan &plan, uint32_t callback_len, uint32_t *step_ms, uint32_t *half_ms)
+{
+    const float ms_of_frame = plan.ms_per_sample * (float)callback_len; // mod.rs:78
+    *half_ms = bd_f32_as_u32(ms_of_frame / 2.0f);                        // mod.rs:81
+    *step_ms = bd_f32_as_u32(ms_of_frame);                               // mod.rs:83
+}
+
+// ---- StrategyKind metadata ------------------------------------------------------------
+extern "C" int bd_kind_count(void) { return 2; }
+
+extern "C" const char *bd_kind_name(int kind)
+{
+    switch (kind) {
+    case BD_KIND_LPF: return "Simple Lowpass Filter";         // lpf.rs:93
+    case BD_KIND_SPECTRUM: return "Simple Spectrum Analysis"; // spectrum.rs:110
+    default: return NULL;
+    }
+}
+
+extern "C" const char *bd_kind_description(int kind)
+{
+    switch (kind) {
+    case BD_KIND_LPF: // lpf.rs:100-102
+        return "A simple beat detection using a lowpass filter. It's not smart enough "
+               "to cope with 'complex' music, like most of today's pop. But it will give "
+               "pretty good results in 'easy' music, like most of 90s pop hits.";
+    case BD_KIND_SPECTRUM: // spectrum.rs:117-119
+        return "A simple beat detection using a spectrum analysis. It's not smart enough "
+               "to cope with 'complex' music, like most of today's pop. But it will give "
+               "pretty good results in 'easy' music, like most of 90s pop hits.";
+    default: return NULL;
+    }
+}
+
+extern "C" uint32_t bd_kind_min_duration_between_beats_ms(int kind)
+{
+    return (kind == BD_KIND_LPF || kind == BD_KIND_SPECTRUM) ? 400u : 0u; // spectrum.rs:130, lpf.rs:113
+}
+
+// ---- batched analysis ---------------------------------------------------------------------
+extern "C" uint64_t bd_batch_callbacks(uint64_t n_samples, uint32_t callback_len)
+{
+    return callback_len ? n_samples / callback_len : 0; // src/lib.rs:276
+}
+
+extern "C" uint32_t bd_batch_max_beats(uint32_t kind, uint32_t sampling_rate, const bd_params *params,
+                                       uint64_t n_samples, uint32_t callback_len)
+{
+    bd_plan plan;
+    if (callback_len == 0 || bd_make_plan((int)kind, sampling_rate, params, &plan) != BD_OK) return 0;
+    const uint64_t n_cb = n_samples / callback_len;
+    uint32_t step, half;
+    bd_clock_step(plan, callback_len, &step, &half);
+    if (step == 0 || plan.gap_ms == 0) return (uint32_t)(n_cb > 0xffffffffull ? 0xffffffffull : n_cb);
+    // two beats are at least ceil(gap/step) callbacks apart
+    const uint64_t spacing = (plan.gap_ms + step - 1) / step;
+    const uint64_t bound = n_cb / spacing + 2;
+    return (uint32_t)(bound > n_cb ? n_cb : bound);
+}
+
+static int bd_check_batch_args(const int16_t *samples, uint64_t n_samples, uint64_t stride,
+                               uint32_t callback_len, const uint8_t *flags)
+{
+    if (!samples || !flags) { bd_set_error("samples and flags must not be NULL"); return BD_ERR_INVALID_ARG; }
+    if (callback_len == 0) { bd_set_error("callback_len must be >= 1 (the reference panics on an empty window)"); return BD_ERR_EMPTY_WINDOW; }
+    if (stride < n_samples) { bd_set_error("stream_stride (%llu) < n_samples (%llu)", (unsigned long long)stride, (unsigned long long)n_samples); return BD_ERR_INVALID_ARG; }
+    return BD_OK;
+}
+
+static int bd_candidates_impl(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
+                              uint64_t n_samples, uint64_t stride, uint32_t callback_len,
+                              float *values, uint8_t *flags, hipStream_t st)
+{
+    if (plan.kind == BD_KIND_SPECTRUM)
+        return bd_launch_spectrum(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, st);
+    return bd_launch_lpf(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, st);
+}
+
+extern "C" int bd_batch_candidates(int kind, uint32_t sampling_rate, const bd_params *params,
+                                   const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                                   uint64_t stream_stride, uint32_t callback_len,
+                                   float *values, uint8_t *flags, void *hip_stream)
+{
+    bd_plan plan;
+    int s = bd_make_plan(kind, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    s = bd_check_batch_args(samples, n_samples, stream_stride, callback_len, flags);
+    if (s != BD_OK) return s;
+    return bd_candidates_impl(plan, samples, n_streams, n_samples, stream_stride, callback_len,
+                              values, flags, (hipStream_t)hip_stream);
+}
+
+extern "C" int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t callback_len,
+                             const uint8_t *flags, uint64_t n_streams, uint64_t n_callbacks,
+                             uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                             uint32_t max_beats, void *hip_stream)
+{
+    bd_plan plan;
+    int s = bd_make_plan(BD_KIND_LPF, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    if (!flags || !beat_count || callback_len == 0) { bd_set_error("bd_refractory: bad arguments"); return BD_ERR_INVALID_ARG; }
+    return bd_launch_refractory(plan, callback_len, flags, n_streams, n_callbacks, beat_count,
+                                beat_idx, beat_ms, max_beats, (hipStream_t)hip_stream);
+}
+
+extern "C" int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
+                                const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                                uint64_t stream_stride, uint32_t callback_len,
+                                float *values, uint8_t *flags,
+                                uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                                uint32_t max_beats, void *hip_stream)
+{
+    bd_plan plan;
+    int s = bd_make_plan(kind, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    s = bd_check_batch_args(samples, n_samples, stream_stride, callback_len, flags);
+    if (s != BD_OK) return s;
+    if (!beat_count) { bd_set_error("beat_count must not be NULL"); return BD_ERR_INVALID_ARG; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    s = bd_candidates_impl(plan, samples, n_streams, n_samples, stream_stride, callback_len, values, flags, st);
+    if (s != BD_OK) return s;
+    const char *k = bd_last_kernel; // keep the dominant kernel's name
+    s = bd_launch_refractory(plan, callback_len, flags, n_streams, n_samples / callback_len,
+                             beat_count, beat_idx, beat_ms, max_beats, st);
+    bd_last_kernel = k;
+    return s;
+}
+
+// device buffers of one host-pointer call
+struct bd_host_job {
+    int16_t *d_samples = nullptr; float *d_values = nullptr; uint8_t *d_flags = nullptr;
+    uint32_t *d_count = nullptr, *d_idx = nullptr, *d_ms = nullptr;
+    hipStream_t st = nullptr;
+    void release()
+    {
+        if (d_samples) (void)hipFree(d_samples);
+        if (d_values) (void)hipFree(d_values);
+        if (d_flags) (void)hipFree(d_flags);
+        if (d_count) (void)hipFree(d_count);
+        if (d_idx) (void)hipFree(d_idx);
+        if (d_ms) (void)hipFree(d_ms);
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const bd_params *params,
+                       const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                       uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
+                       uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
+{
+    const uint64_t n_cb = n_samples / callback_len;
+    const uint64_t n_out = n_streams * n_cb;
+    // rows are repacked to a 16-byte aligned device stride so the fast kernels apply
+    const uint64_t d_stride = (n_samples + 7) & ~7ull;
+    BD_HIP(hipStreamCreateWithFlags(&j.st, hipStreamNonBlocking));
+    BD_HIP(hipMalloc((void **)&j.d_samples, (n_streams * d_stride + 8) * sizeof(int16_t)));
+    if (n_out) {
+        BD_HIP(hipMalloc((void **)&j.d_flags, n_out));
+        if (values) BD_HIP(hipMalloc((void **)&j.d_values, n_out * sizeof(float)));
+    }
+    BD_HIP(hipMalloc((void **)&j.d_count, (n_streams + 1) * sizeof(uint32_t)));
+    if (max_beats && beat_idx) BD_HIP(hipMalloc((void **)&j.d_idx, n_streams * max_beats * sizeof(uint32_t)));
+    if (max_beats && beat_ms) BD_HIP(hipMalloc((void **)&j.d_ms, n_streams * max_beats * sizeof(uint32_t)));
+    BD_HIP(hipMemcpy2DAsync(j.d_samples, d_stride * sizeof(int16_t), samples, stride * sizeof(int16_t),
+                            n_samples * sizeof(int16_t), n_streams, hipMemcpyHostToDevice, j.st));
+    if (n_out == 0) {
+        BD_HIP(hipMemsetAsync(j.d_count, 0, n_streams * sizeof(uint32_t), j.st));
+    } else {
+        int s = bd_analyze_batch(kind, sampling_rate, params, j.d_samples, n_streams, n_samples, d_stride,
+                                 callback_len, j.d_values, j.d_flags, j.d_count, j.d_idx, j.d_ms,
+                                 max_beats, j.st);
+        if (s != BD_OK) return s;
+        if (values) BD_HIP(hipMemcpyAsync(values, j.d_values, n_out * sizeof(float), hipMemcpyDeviceToHost, j.st));
+        if (flags) BD_HIP(hipMemcpyAsync(flags, j.d_flags, n_out, hipMemcpyDeviceToHost, j.st));
+    }
+    BD_HIP(hipMemcpyAsync(beat_count, j.d_count, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
+    if (j.d_idx) BD_HIP(hipMemcpyAsync(beat_idx, j.d_idx, n_streams * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
+    if (j.d_ms) BD_HIP(hipMemcpyAsync(beat_ms, j.d_ms, n_streams * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
+    BD_HIP(hipStreamSynchronize(j.st));
+    return BD_OK;
+}
+
+extern "C" int bd_analyze_batch_host(int kind, uint32_t sampling_rate, const bd_params *params,
+                                     const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                                     uint64_t stream_stride, uint32_t callback_len,
+                                     float *values, uint8_t *flags,
+                                     uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                                     uint32_t max_beats, int device)
+{
+    bd_plan plan;
+    int s = bd_make_plan(kind, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    if (!samples || !beat_count) { bd_set_error("samples and beat_count must not be NULL"); return BD_ERR_INVALID_ARG; }
+    if (callback_len == 0) { bd_set_error("callback_len must be >= 1"); return BD_ERR_EMPTY_WINDOW; }
+    if (stream_stride < n_samples) { bd_set_error("stream_stride < n_samples"); return BD_ERR_INVALID_ARG; }
+    if (n_streams == 0) return BD_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        bd_set_error("no HIP device available (this library has no CPU path)");
+        return BD_ERR_NO_DEVICE;
+    }
+    int prev = 0;
+    BD_HIP(hipGetDevice(&prev));
+    if (device < 0) device = prev;
+    if (device >= count) { bd_set_error("device %d out of range (%d devices)", device, count); return BD_ERR_INVALID_ARG; }
+    if (device != prev) BD_HIP(hipSetDevice(device));
+    bd_host_job j;
+    s = bd_host_run(j, kind, sampling_rate, params, samples, n_streams, n_samples, stream_stride,
+                    callback_len, values, flags, beat_count, beat_idx, beat_ms, max_beats);
+    j.release();
+    if (device != prev) (void)hipSetDevice(prev);
+    return s;
+}
+
+extern "C" int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd_params *params,
+                                      const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                                      uint64_t stream_stride, uint32_t callback_len,
+                                      float *values, uint8_t *flags,
+                                      uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                                      uint32_t max_beats, const int *devices, int n_devices)
+{
+    if (!devices || n_devices <= 0) { bd_set_error("bd_analyze_batch_multi: empty device list"); return BD_ERR_INVALID_ARG; }
+    if (callback_len == 0) { bd_set_error("callback_len must be >= 1"); return BD_ERR_EMPTY_WINDOW; }
+    const uint64_t n_cb = n_samples / callback_len;
+    std::vector<int> status((size_t)n_devices, BD_OK);
+    std::vector<std::string> messages((size_t)n_devices);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < n_devices; g++) {
+        // contiguous stream ranges, no data shared between devices
+        const uint64_t s0 = n_streams * (uint64_t)g / (uint64_t)n_devices;
+        const uint64_t s1 = n_streams * (uint64_t)(g + 1) / (uint64_t)n_devices;
+        workers.emplace_back([=, &status, &messages] {
+            if (s1 == s0) return;
+            status[(size_t)g] = bd_analyze_batch_host(
+                kind, sampling_rate, params, samples + s0 * stream_stride, s1 - s0, n_samples,
+                stream_stride, callback_len,
+                values ? values + s0 * n_cb : nullptr, flags ? flags + s0 * n_cb : nullptr,
+                beat_count + s0, beat_idx ? beat_idx + s0 * max_beats : nullptr,
+                beat_ms ? beat_ms + s0 * max_beats : nullptr, max_beats, devices[g]);
+            if (status[(size_t)g] != BD_OK) messages[(size_t)g] = bd_last_error();
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (int g = 0; g < n_devices; g++)
+        if (status[(size_t)g] != BD_OK) {
+            bd_set_error("device %d: %s", devices[g], messages[(size_t)g].c_str());
+            return status[(size_t)g];
+        }
+    return BD_OK;
+}

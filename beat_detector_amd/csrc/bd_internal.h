@@ -1,0 +1,136 @@
+// Internal declarations shared by the translation units of libbeatdet_hip.so.
+#ifndef BD_INTERNAL_H
+#define BD_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/beat_detector_hip.h"
+
+#define BD_RING_LEN 1024  // src/strategies/spectrum.rs:43
+#define BD_HALF_BLOCK 512 // granule of the fast Spectrum kernel
+
+// Everything the kernels need, derived once on the host from
+// (kind, sampling_rate, bd_params) with the reference's f32 arithmetic.
+struct bd_plan {
+    int      kind;
+    uint32_t sampling_rate;
+    float    ms_per_sample;   // src/strategies/mod.rs:64
+    uint32_t min_amp;
+    uint32_t gap_ms;
+    // Spectrum
+    int      first_bin, last_bin, n_bins;
+    float    divisor;         // 0 => no scaling
+    float    threshold;
+    uint32_t dc_packs_nyquist;
+    // LPF
+    float    alpha;
+    int      alpha_valid;
+    float    lpf_ratio;
+};
+
+int  bd_make_plan(int kind, uint32_t sampling_rate, const bd_params *params, bd_plan *plan);
+void bd_clock_step(const bd_plan &plan, uint32_t callback_len, uint32_t *step_ms, uint32_t *half_ms);
+
+void bd_set_error(const char *fmt, ...);
+void bd_set_last_kernel(const char *name);
+int  bd_check_hip(hipError_t e, const char *what);
+
+#define BD_HIP(call) do { int _s = bd_check_hip((call), #call); if (_s != BD_OK) return _s; } while (0)
+
+// stage launchers (device pointers, enqueue only)
+int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
+                       uint64_t n_samples, uint64_t stride, uint32_t callback_len,
+                       float *values, uint8_t *flags, hipStream_t st);
+int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
+                  uint64_t n_samples, uint64_t stride, uint32_t callback_len,
+                  float *values, uint8_t *flags, hipStream_t st);
+int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8_t *flags,
+                         uint64_t n_streams, uint64_t n_cb, uint32_t *beat_count,
+                         uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
+                         hipStream_t st);
+
+// Rust `as` casts on the host
+static inline uint32_t bd_f32_as_u32(float x)
+{
+    if (x != x) return 0;
+    if (x <= 0.0f) return 0;
+    if (x >= 4294967296.0f) return 4294967295u;
+    return (uint32_t)x;
+}
+
+// ---- device helpers -------------------------------------------------------
+#if defined(__HIPCC__)
+
+// 16-byte streaming load (data is read once: keep it out of the way in the caches)
+typedef unsigned int bd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 bd_load_stream16(const void *p)
+{
+    const bd_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const bd_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float bd_dpp_f(float v)
+{
+    return __builtin_bit_cast(float,
+        __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int bd_dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+// all-reduce inside each row of 16 lanes (row_ror 8,4,2,1)
+__device__ __forceinline__ float bd_row_sum(float v)
+{
+    v += bd_dpp_f<0x128>(v); v += bd_dpp_f<0x124>(v);
+    v += bd_dpp_f<0x122>(v); v += bd_dpp_f<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ int bd_row_sum(int v)
+{
+    v += bd_dpp_i<0x128>(v); v += bd_dpp_i<0x124>(v);
+    v += bd_dpp_i<0x122>(v); v += bd_dpp_i<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ float bd_row_max(float v)
+{
+    v = fmaxf(v, bd_dpp_f<0x128>(v)); v = fmaxf(v, bd_dpp_f<0x124>(v));
+    v = fmaxf(v, bd_dpp_f<0x122>(v)); v = fmaxf(v, bd_dpp_f<0x121>(v));
+    return v;
+}
+
+// value of lane 15 of the previous row for rows 1..3; `row0` for row 0
+__device__ __forceinline__ float bd_prev_row(float cur, float row0)
+{
+    return __builtin_bit_cast(float,
+        __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, row0), __builtin_bit_cast(int, cur),
+                                    0x142 /*row_bcast:15*/, 0xe, 0xf, false));
+}
+__device__ __forceinline__ int bd_prev_row(int cur, int row0)
+{
+    return __builtin_amdgcn_update_dpp(row0, cur, 0x142, 0xe, 0xf, false);
+}
+__device__ __forceinline__ float bd_lane63(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int bd_lane63(int v) { return __builtin_amdgcn_readlane(v, 63); }
+
+// full-wave reductions (butterfly through the LDS crossbar; used off the hot path)
+__device__ __forceinline__ float bd_wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float bd_wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+#endif // __HIPCC__
+#endif

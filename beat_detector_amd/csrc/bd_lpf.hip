@@ -1,0 +1,183 @@
+// LPF strategy, batched: for every callback (window) of every stream, the
+// decision of src/strategies/lpf.rs:60-75 -- amplitude gate, single-pole
+// low-pass over a fresh copy of the window (the filter restarts every window,
+// lpf.rs:66), threshold (0.77 * max) as i16, any(|y| >= threshold).
+//
+// The recurrence truncates to i16 at every step (the filter runs in place on
+// an i16 buffer), so it is not linear and is evaluated exactly in order:
+//     y = trunc( y + alpha * (x - y) ),  y(-1) = 0
+// with separate f32 multiply and add (no fused multiply-add; this file must be
+// compiled with -ffp-contract=off).  Windows are independent, so one lane owns
+// one window and 64 consecutive windows of a stream form a wavefront's task.
+// To keep HBM reads coalesced, the wavefront loads 64 samples of each of its 64
+// windows at a time (8 windows x 128 B per load instruction), transposes them
+// through a private LDS tile (144-byte rows: conflict-free ds_read_b128), and
+// prefetches the next chunk into registers while it filters the current one.
+// The kernel is bound by HBM bandwidth: 2 bytes read per sample, ~6 VALU
+// operations per sample.
+#include "bd_internal.h"
+
+struct bd_lpf_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride;      // samples between streams
+    uint64_t       n_cb;        // callbacks per stream
+    uint64_t       n_tasks;     // n_streams * groups_per_stream
+    uint32_t       groups_per_stream; // ceil(n_cb / 64)
+    uint32_t       callback_len;
+    uint32_t       min_amp;
+    float          alpha;
+    float          ratio;
+};
+
+#define BD_LPF_CHUNK 64          // samples per window per chunk
+#define BD_LPF_ROW_U4 9          // LDS row = 8 x 16 B of data + 16 B of padding
+
+__device__ __forceinline__ void bd_lpf_step(float x, float alpha, float &y, float &ymax, float &xmax)
+{
+    const float d = x - y;
+    const float m = alpha * d;
+    const float s = y + m;
+    y = truncf(s);
+    ymax = fmaxf(ymax, fabsf(y));
+    xmax = fmaxf(xmax, fabsf(x));
+}
+
+__device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, uint64_t j, bool valid,
+                                              float xmax, float ymax)
+{
+    if (!valid) return;
+    const float wmax = fminf(xmax, 32767.f);                 // window_stats.rs:47
+    const bool gate = wmax >= (float)a.min_amp;              // lib.rs:135
+    // (ratio * max as f32) as i16: truncate, saturate, NaN -> 0  (lpf.rs:74)
+    float thr = truncf(a.ratio * wmax);
+    thr = (thr != thr) ? 0.f : fminf(fmaxf(thr, -32768.f), 32767.f);
+    const bool flag = gate && (ymax >= thr);                 // lpf.rs:75
+    const uint64_t o = s * a.n_cb + j;
+    if (a.values) a.values[o] = gate ? ymax : 0.f;
+    a.flags[o] = flag ? 1 : 0;
+}
+
+// ALIGNED: callback_len % 8 == 0, stride % 8 == 0, base 16-byte aligned.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
+{
+    __shared__ uint4 tile_all[4][64 * BD_LPF_ROW_U4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint4 *tile = tile_all[wave];
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    if (task >= a.n_tasks) return; // wave-uniform
+    const uint64_t s = task / a.groups_per_stream;
+    const uint64_t j0 = (task - s * a.groups_per_stream) * 64;
+    const uint32_t L = a.callback_len;
+    const int16_t *gp = a.samples + s * a.stride + j0 * L; // first window of the group
+    const uint64_t rows = (a.n_cb - j0 < 64) ? (a.n_cb - j0) : 64;
+    const bool valid = (uint64_t)lane < rows;
+    const uint32_t n_chunks = (L + BD_LPF_CHUNK - 1) / BD_LPF_CHUNK;
+
+    float y = 0.f, ymax = 0.f, xmax = 0.f;
+    const float alpha = a.alpha;
+
+    if (ALIGNED) {
+        // load instruction i covers windows 8 i + lane/8, 16-byte piece lane%8
+        const int lrow = lane >> 3, piece = lane & 7;
+        uint4 stage[8];
+        auto load_chunk = [&](uint32_t ch) {
+            const uint32_t first = ch * BD_LPF_CHUNK + piece * 8; // sample offset inside the window
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t row = 8 * i + lrow;
+                if (row < rows && first < L)
+                    stage[i] = bd_load_stream16(gp + (uint64_t)row * L + first);
+                else
+                    stage[i] = make_uint4(0, 0, 0, 0);
+            }
+        };
+        load_chunk(0);
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            // all lanes have finished reading the previous chunk (LDS operations of
+            // one wavefront complete in order); keep the compiler from reordering
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                tile[(8 * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
+            if (ch + 1 < n_chunks) load_chunk(ch + 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t left = L - ch * BD_LPF_CHUNK;
+            const int pieces = left >= BD_LPF_CHUNK ? 8 : (int)(left / 8);
+            for (int p = 0; p < pieces; p++) {
+                const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
+        }
+    } else {
+        // element-wise staging: lane = sample inside the chunk, loop over rows
+        int16_t *tile16 = reinterpret_cast<int16_t *>(tile);
+        const int row_i16 = BD_LPF_ROW_U4 * 8;
+        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+            const uint32_t off = ch * BD_LPF_CHUNK + lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t row = 0; row < rows; row++)
+                tile16[row * row_i16 + lane] = off < L ? gp[(uint64_t)row * L + off] : (int16_t)0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t left = L - ch * BD_LPF_CHUNK;
+            const int cnt = left >= BD_LPF_CHUNK ? BD_LPF_CHUNK : (int)left;
+            for (int i = 0; i < cnt; i++)
+                bd_lpf_step((float)tile16[lane * row_i16 + i], alpha, y, ymax, xmax);
+        }
+    }
+    bd_lpf_finish(a, s, j0 + lane, valid, xmax, ymax);
+}
+
+__global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { if (values) values[i] = 0.f; flags[i] = 0; }
+}
+
+int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
+                  uint64_t n_samples, uint64_t stride, uint32_t callback_len,
+                  float *values, uint8_t *flags, hipStream_t st)
+{
+    const uint64_t n_cb = n_samples / callback_len;
+    if (n_cb == 0 || n_streams == 0) return BD_OK;
+    if (!plan.alpha_valid) {
+        // alpha is NaN (sampling rate wraps to 0 as u16, lpf.rs:69): every
+        // filtered sample becomes 0 and no window can reach its threshold
+        const uint64_t n = n_streams * n_cb;
+        const uint64_t grid64 = (n + 255) / 256;
+        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(bd_fill_zero_kernel, dim3((unsigned)grid64), dim3(256), 0, st, values, flags, n);
+        bd_set_last_kernel("bd_fill_zero_kernel");
+        return bd_check_hip(hipGetLastError(), "launch bd_fill_zero_kernel");
+    }
+    bd_lpf_args a;
+    a.samples = samples; a.values = values; a.flags = flags;
+    a.stride = stride; a.n_cb = n_cb;
+    const uint64_t groups = (n_cb + 63) / 64;
+    if (groups > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
+    a.groups_per_stream = (uint32_t)groups;
+    a.n_tasks = n_streams * groups;
+    a.callback_len = callback_len; a.min_amp = plan.min_amp;
+    a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
+    const uint64_t grid64 = (a.n_tasks + 3) / 4;
+    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0);
+    if (aligned)
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((bd_lpf_window_kernel<false>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+    bd_set_last_kernel("bd_lpf_window_kernel");
+    return bd_check_hip(hipGetLastError(), "launch bd_lpf_window_kernel");
+}

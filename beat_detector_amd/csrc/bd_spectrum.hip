@@ -1,0 +1,321 @@
+// Spectrum strategy, batched: for every callback of every stream, the value the
+// reference computes at src/strategies/spectrum.rs:82-92 -- the largest
+// magnitude among the bins of a 1024-point DFT of the latest 1024 samples whose
+// frequency is <= 90 Hz, scaled by `divide_by_N` -- and the decision
+// "amplitude gate passed (spectrum.rs:77-80) and value > threshold (:92)".
+//
+// Only bins 0..2 are ever kept at audio sampling rates (k * fs/1024 <= 90 Hz),
+// so no full FFT is evaluated: the kept bins are computed as a pruned DFT, one
+// HBM read per sample.  Nothing here is a dense contraction; the kernel is
+// bound by HBM bandwidth.
+//
+// Fast kernel (callback length 512 or 1024, 16-byte aligned rows)
+//   Samples are consumed in half-blocks of 512.  With
+//       P_k(h) = sum_{n<512} x[512 h + n] W^{k n},   W = exp(-2 pi i / 1024)
+//   the DFT of the ring [half-block h-1 | half-block h] is
+//       X_k = P_k(h-1) + (-1)^k P_k(h)               (W^{512 k} = (-1)^k)
+//   so overlapping callbacks (hop 512) share partial sums and every sample is
+//   read once.  A wavefront walks a run of consecutive half-blocks of one
+//   stream, four per iteration: row g (16 lanes) owns half-block 4*it+g, lane l
+//   of the row loads 4 x 16 B (samples 128 c + 8 l + m, c < 4, m < 8), so each
+//   row reads 256 contiguous bytes per load instruction.  Per lane the twiddle
+//   is split as W^{k(128c+m)} (compile-time constants shared by all lanes)
+//   times W^{8 k l} (one complex multiply per lane per half-block).  Partial
+//   sums are reduced inside the row with DPP row rotations; the previous
+//   half-block's sums come from the row above (row_bcast:15) or, for row 0,
+//   from the previous iteration (v_readlane 63).
+//
+// Generic kernel (any callback length, alignment or bin count)
+//   One wavefront per callback, ring gathered with 2-byte loads, twiddles from
+//   a 1024-entry table.
+#include "bd_internal.h"
+#include "bd_twiddles.inc"
+
+typedef short bd_short2 __attribute__((ext_vector_type(2)));
+
+struct bd_spec_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride;          // samples between streams
+    uint64_t       n_tasks;         // n_streams * runs_per_stream
+    uint64_t       n_cb;            // callbacks per stream
+    uint32_t       n_hb;            // half-blocks per stream that belong to callbacks
+    uint32_t       run_hbs;         // half-blocks per task (multiple of 4)
+    uint32_t       runs_per_stream;
+    uint32_t       min_amp;
+    uint32_t       include_dc;
+    float          divisor;
+    float          threshold;
+};
+
+static __device__ const float bd_cos1024[1024] = {
+#include "bd_cos1024.inc"
+};
+static __device__ const float bd_sin1024[1024] = {
+#include "bd_sin1024.inc"
+};
+
+__device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int64_t hb, int l, bool valid)
+{
+    const uint4 *p = reinterpret_cast<const uint4 *>(sp + hb * BD_HALF_BLOCK) + l;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (valid) d[c] = bd_load_stream16(p + 16 * c);
+        else d[c] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
+// NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
+template <int MODE, int NK, bool NYQ>
+__global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, l = lane & 15;
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (task >= a.n_tasks) return; // wave-uniform
+    const uint64_t s = task / a.runs_per_stream;
+    const uint32_t r = (uint32_t)(task - s * a.runs_per_stream);
+    const int64_t hb0 = (int64_t)r * a.run_hbs;
+    const int16_t *sp = a.samples + s * a.stride;
+    const int64_t n_hb = a.n_hb;
+    const int n_it = (int)(a.run_hbs / 4);
+    // hop 512: the first callback of a run needs the half-block before the run
+    const int it_begin = (MODE == 0 && hb0 > 0) ? -1 : 0;
+    const int64_t hb_lo = (MODE == 0) ? hb0 - 1 : hb0;
+
+    const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
+    const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
+
+    // carried sums of the last half-block of the previous iteration
+    float c_re1 = 0.f, c_im1 = 0.f, c_re2 = 0.f, c_im2 = 0.f, c_amax = 0.f;
+    int c_dc = 0, c_ny = 0;
+
+    uint4 cur[4], nxt[4];
+    {
+        int64_t hb = hb0 + 4 * (int64_t)it_begin + g;
+        bd_load_hb(cur, sp, hb, l, hb >= hb_lo && hb >= 0 && hb < n_hb);
+    }
+    for (int it = it_begin; it < n_it; it++) {
+        const int64_t hb = hb0 + 4 * (int64_t)it + g;
+        if (hb0 + 4 * (int64_t)it >= n_hb) break; // wave-uniform
+        {
+            int64_t hbn = hb + 4;
+            bool vn = (it + 1 < n_it) && hbn >= hb_lo && hbn < n_hb;
+            bd_load_hb(nxt, sp, hbn, l, vn);
+        }
+        float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
+        int dc = 0, ny = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const unsigned w[4] = {cur[c].x, cur[c].y, cur[c].z, cur[c].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int d = (int)w[q];
+                const float x0 = (float)(short)(d & 0xffff);
+                const float x1 = (float)(short)(d >> 16);
+                const int i0 = c * 8 + 2 * q, i1 = i0 + 1;
+                dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, d), bd_short2{1, 1}, dc, false);
+                if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, d), bd_short2{1, -1}, ny, false);
+                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+                if (NK >= 1) {
+                    a1 = __builtin_fmaf(x0, BD_TW_C[0][i0], a1); b1 = __builtin_fmaf(x0, BD_TW_S[0][i0], b1);
+                    a1 = __builtin_fmaf(x1, BD_TW_C[0][i1], a1); b1 = __builtin_fmaf(x1, BD_TW_S[0][i1], b1);
+                }
+                if (NK >= 2) {
+                    a2 = __builtin_fmaf(x0, BD_TW_C[1][i0], a2); b2 = __builtin_fmaf(x0, BD_TW_S[1][i0], b2);
+                    a2 = __builtin_fmaf(x1, BD_TW_C[1][i1], a2); b2 = __builtin_fmaf(x1, BD_TW_S[1][i1], b2);
+                }
+            }
+        }
+        // (a - i b) * (cos - i sin): apply the per-lane offset 8 l, then reduce the row
+        float re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f;
+        if (NK >= 1) {
+            re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
+            im1 = bd_row_sum(a1 * ls1 + b1 * lc1);
+        }
+        if (NK >= 2) {
+            re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
+            im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
+        }
+        dc = bd_row_sum(dc);
+        if (NYQ) ny = bd_row_sum(ny);
+        amax = bd_row_max(amax);
+
+        // sums of the half-block just before this row's
+        const float p_re1 = bd_prev_row(re1, c_re1), p_im1 = bd_prev_row(im1, c_im1);
+        const float p_re2 = bd_prev_row(re2, c_re2), p_im2 = bd_prev_row(im2, c_im2);
+        const float p_amax = bd_prev_row(amax, c_amax);
+        const int p_dc = bd_prev_row(dc, c_dc);
+        const int p_ny = NYQ ? bd_prev_row(ny, c_ny) : 0;
+        c_re1 = bd_lane63(re1); c_im1 = bd_lane63(im1);
+        c_re2 = bd_lane63(re2); c_im2 = bd_lane63(im2);
+        c_amax = bd_lane63(amax); c_dc = bd_lane63(dc);
+        if (NYQ) c_ny = bd_lane63(ny);
+
+        // X_k = P_k(prev) + (-1)^k P_k(cur)
+        const float x_dc = (float)(p_dc + dc);
+        float m0 = fabsf(x_dc);
+        if (NYQ) {
+            const float x_ny = (float)(p_ny + ny);
+            m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
+        }
+        float best = a.include_dc ? m0 : 0.f;
+        if (NK >= 1) {
+            const float xr = p_re1 - re1, xi = p_im1 - im1;
+            const float m1 = sqrtf(xr * xr + xi * xi);
+            best = fmaxf(best, m1);
+        }
+        if (NK >= 2) {
+            const float xr = p_re2 + re2, xi = p_im2 + im2;
+            const float m2 = sqrtf(xr * xr + xi * xi);
+            best = fmaxf(best, m2);
+        }
+        const float value = (a.divisor == 0.f) ? best : best / a.divisor;
+        const float wmax = fminf(MODE == 0 ? amax : fmaxf(amax, p_amax), 32767.f);
+        const bool gate = wmax >= (float)a.min_amp;
+        const bool flag = gate && (value > a.threshold);
+
+        bool writer = (l == 0) && it >= 0 && hb < n_hb;
+        uint64_t cb;
+        if (MODE == 0) cb = (uint64_t)hb;
+        else { writer = writer && (g & 1); cb = (uint64_t)(hb >> 1); }
+        if (writer) {
+            const uint64_t o = s * a.n_cb + cb;
+            if (a.values) a.values[o] = value;
+            a.flags[o] = flag ? 1 : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) cur[c] = nxt[c];
+    }
+}
+
+// ---- generic path ---------------------------------------------------------
+struct bd_spec_generic_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride;
+    uint64_t       n_cb;
+    uint64_t       n_total;  // n_streams * n_cb
+    uint32_t       callback_len;
+    uint32_t       min_amp;
+    int            first_bin, last_bin;
+    uint32_t       nyq;
+    float          divisor;
+    float          threshold;
+};
+
+__global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generic_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.n_total) return;
+    const uint64_t s = t / a.n_cb, j = t - s * a.n_cb;
+    const int16_t *sp = a.samples + s * a.stride;
+    const int64_t end = (int64_t)(j + 1) * a.callback_len;
+    // ring = samples [end-1024, end), zeros before the stream starts (spectrum.rs:50-51)
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int64_t idx = end - BD_RING_LEN + lane + 64 * i;
+        x[i] = idx >= 0 ? (float)sp[idx] : 0.f;
+    }
+    // amplitude gate over the callback's own samples (spectrum.rs:77)
+    float amax = 0.f;
+    for (int64_t idx = end - a.callback_len + lane; idx < end; idx += 64)
+        amax = fmaxf(amax, fabsf((float)sp[idx]));
+    amax = fminf(bd_wave_max(amax), 32767.f);
+    float best = 0.f;
+    bool first = true;
+    for (int k = a.first_bin; k <= a.last_bin; k++) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int m = (k * (lane + 64 * i)) & (BD_RING_LEN - 1);
+            re = __builtin_fmaf(x[i], bd_cos1024[m], re);
+            im = __builtin_fmaf(x[i], bd_sin1024[m], im);
+        }
+        re = bd_wave_sum(re);
+        im = bd_wave_sum(im);
+        if (k == 0 && a.nyq) {
+            float ny = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) ny += (lane & 1) ? -x[i] : x[i];
+            im = bd_wave_sum(ny);
+        }
+        const float mag = sqrtf(re * re + im * im);
+        best = first ? mag : fmaxf(best, mag);
+        first = false;
+    }
+    const float value = (a.divisor == 0.f) ? best : best / a.divisor;
+    const bool flag = (amax >= (float)a.min_amp) && (value > a.threshold);
+    if (lane == 0) {
+        if (a.values) a.values[t] = value;
+        a.flags[t] = flag ? 1 : 0;
+    }
+}
+
+// ---- launcher ---------------------------------------------------------------
+template <int MODE, int NK>
+static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, hipStream_t st)
+{
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true>), dim3(grid), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
+                       uint64_t n_samples, uint64_t stride, uint32_t callback_len,
+                       float *values, uint8_t *flags, hipStream_t st)
+{
+    const uint64_t n_cb = n_samples / callback_len;
+    if (n_cb == 0 || n_streams == 0) return BD_OK;
+    const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0);
+    const bool fast_len = callback_len == 512 || callback_len == 1024;
+    const bool fast_bins = plan.last_bin <= 2;
+    if (aligned && fast_len && fast_bins) {
+        bd_spec_args a;
+        a.samples = samples; a.values = values; a.flags = flags;
+        a.stride = stride; a.n_cb = n_cb;
+        const uint64_t n_hb = n_cb * (callback_len / BD_HALF_BLOCK);
+        if (n_hb > 0xffffffffull) { bd_set_error("stream too long for the fast Spectrum kernel"); return BD_ERR_UNSUPPORTED; }
+        a.n_hb = (uint32_t)n_hb;
+        // run length: long runs amortise the one re-read half-block at each run
+        // start; short streams still need enough wavefronts to fill 256 CUs.
+        uint32_t run = 128;
+        while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
+        a.run_hbs = run;
+        a.runs_per_stream = (uint32_t)((n_hb + run - 1) / run);
+        a.n_tasks = n_streams * a.runs_per_stream;
+        a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
+        a.divisor = plan.divisor; a.threshold = plan.threshold;
+        const uint64_t grid64 = (a.n_tasks + 3) / 4;
+        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        const unsigned grid = (unsigned)grid64;
+        const int nk = plan.last_bin; // bins 1..last_bin
+        const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
+        if (callback_len == 512) {
+            if (nk == 0) launch_fast<0, 0>(nyq, a, grid, st);
+            else if (nk == 1) launch_fast<0, 1>(nyq, a, grid, st);
+            else launch_fast<0, 2>(nyq, a, grid, st);
+        } else {
+            if (nk == 0) launch_fast<1, 0>(nyq, a, grid, st);
+            else if (nk == 1) launch_fast<1, 1>(nyq, a, grid, st);
+            else launch_fast<1, 2>(nyq, a, grid, st);
+        }
+        bd_set_last_kernel("bd_spectrum_band_kernel");
+        return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");
+    }
+    bd_spec_generic_args a;
+    a.samples = samples; a.values = values; a.flags = flags;
+    a.stride = stride; a.n_cb = n_cb; a.n_total = n_streams * n_cb;
+    a.callback_len = callback_len; a.min_amp = plan.min_amp;
+    a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
+    a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;
+    const uint64_t grid64 = (a.n_total + 3) / 4;
+    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_spectrum_generic_kernel, dim3((unsigned)grid64), dim3(256), 0, st, a);
+    bd_set_last_kernel("bd_spectrum_generic_kernel");
+    return bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
+}

@@ -1,0 +1,136 @@
+// Synthetic click-track generator (device and host twins of one integer-only
+// definition, see bd_synth.h) and the live-path ingest converters.
+#include "bd_internal.h"
+#include "bd_synth.h"
+
+#include <mutex>
+#include <vector>
+
+static __device__ int16_t bd_click_dev[BD_CLICK_LEN];
+
+static const int16_t *bd_click_host()
+{
+    static int16_t click[BD_CLICK_LEN];
+    static std::once_flag once;
+    std::call_once(once, [] { bd_synth_make_click(click); });
+    return click;
+}
+
+__global__ __launch_bounds__(256) void bd_synth_kernel(int16_t *samples, uint64_t n_streams,
+                                                       uint64_t n_samples, uint64_t stride,
+                                                       uint64_t first_stream, uint64_t seed,
+                                                       uint32_t sampling_rate, uint64_t groups_per_stream)
+{
+    // one thread per group of 8 consecutive samples
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_streams * groups_per_stream) return;
+    const uint64_t s = t / groups_per_stream;
+    const uint64_t n0 = (t - s * groups_per_stream) * 8;
+    const bd_synth_stream p = bd_synth_stream_params(seed, first_stream + s, sampling_rate);
+    int16_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = bd_synth_sample(p, bd_click_dev, n0 + i);
+    int16_t *dst = samples + s * stride + n0;
+    if (n0 + 8 <= n_samples && ((uintptr_t)dst % 16 == 0)) {
+        uint4 pk;
+        pk.x = (uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+        pk.y = (uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+        pk.z = (uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
+        pk.w = (uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+        *reinterpret_cast<uint4 *>(dst) = pk;
+    } else {
+        for (int i = 0; i < 8; i++)
+            if (n0 + i < n_samples) dst[i] = v[i];
+    }
+}
+
+extern "C" int bd_synth_fill(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                             uint64_t stream_stride, uint64_t first_stream, uint64_t seed,
+                             uint32_t sampling_rate, void *hip_stream)
+{
+    if (!samples || stream_stride < n_samples || sampling_rate == 0) {
+        bd_set_error("bd_synth_fill: bad arguments"); return BD_ERR_INVALID_ARG;
+    }
+    if (n_streams == 0 || n_samples == 0) return BD_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    // the template is uploaded once per device and process
+    static std::mutex mu;
+    static std::vector<int> done;
+    int dev = 0;
+    BD_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        bool have = false;
+        for (int d : done) have = have || d == dev;
+        if (!have) {
+            BD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(bd_click_dev), bd_click_host(),
+                                     sizeof(int16_t) * BD_CLICK_LEN, 0, hipMemcpyHostToDevice));
+            done.push_back(dev);
+        }
+    }
+    const uint64_t groups = (n_samples + 7) / 8;
+    const uint64_t grid64 = (n_streams * groups + 255) / 256;
+    if (grid64 > 0x7fffffffull) { bd_set_error("bd_synth_fill: batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_synth_kernel, dim3((unsigned)grid64), dim3(256), 0, st,
+                       samples, n_streams, n_samples, stream_stride, first_stream, seed,
+                       sampling_rate, groups);
+    return bd_check_hip(hipGetLastError(), "launch bd_synth_kernel");
+}
+
+extern "C" int bd_synth_fill_host(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                                  uint64_t stream_stride, uint64_t first_stream, uint64_t seed,
+                                  uint32_t sampling_rate)
+{
+    if (!samples || stream_stride < n_samples || sampling_rate == 0) {
+        bd_set_error("bd_synth_fill_host: bad arguments"); return BD_ERR_INVALID_ARG;
+    }
+    const int16_t *click = bd_click_host();
+    for (uint64_t s = 0; s < n_streams; s++) {
+        const bd_synth_stream p = bd_synth_stream_params(seed, first_stream + s, sampling_rate);
+        int16_t *dst = samples + s * stream_stride;
+        for (uint64_t n = 0; n < n_samples; n++) dst[n] = bd_synth_sample(p, click, n);
+    }
+    return BD_OK;
+}
+
+// ---- ingest converters, src/record.rs:151-166 -------------------------------
+__global__ void bd_u16_to_i16_kernel(const uint16_t *in, int16_t *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t x = (int32_t)in[i] - (int32_t)(INT16_MAX / 2); // record.rs:154-155
+    out[i] = (int16_t)(uint16_t)(uint32_t)x;                     // :156 wrapping cast
+}
+
+__global__ void bd_f32_to_i16_kernel(const float *in, int16_t *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i] * 32767.0f;                            // record.rs:163
+    // `as i16`: truncate toward zero, saturate, NaN -> 0        // :164
+    float t = truncf(x);
+    t = (t != t) ? 0.f : fminf(fmaxf(t, -32768.f), 32767.f);
+    out[i] = (int16_t)(int)t;
+}
+
+extern "C" int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, void *hip_stream)
+{
+    if ((!in || !out) && n) { bd_set_error("bd_u16_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
+    if (n == 0) return BD_OK;
+    const uint64_t grid64 = (n + 255) / 256;
+    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bd_u16_to_i16_kernel, dim3((unsigned)grid64), dim3(256), 0,
+                       (hipStream_t)hip_stream, in, out, n);
+    return bd_check_hip(hipGetLastError(), "launch bd_u16_to_i16_kernel");
+}
+
+extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, void *hip_stream)
+{
+    if ((!in || !out) && n) { bd_set_error("bd_f32_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
+    if (n == 0) return BD_OK;
+    const uint64_t grid64 = (n + 255) / 256;
+    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bd_f32_to_i16_kernel, dim3((unsigned)grid64), dim3(256), 0,
+                       (hipStream_t)hip_stream, in, out, n);
+    return bd_check_hip(hipGetLastError(), "launch bd_f32_to_i16_kernel");
+}

@@ -1,0 +1,195 @@
+/*
+ * beat_detector_hip.h -- C ABI of the MI355X (gfx950) implementation of
+ * beat-detector's per-window analysis path.
+ *
+ * The reference (a Rust crate) has no FFI of its own; its boundary for this
+ * path is the `Strategy` trait, the `StrategyKind` enum and
+ * `record::start_listening`.  Each entry point below names the reference
+ * interface it stands in for (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - every function returns an int status (BD_OK or a negative BD_ERR_*),
+ *     never throws, never takes ownership of caller memory;
+ *   - `bd_last_error()` returns a thread-local message for the last failure;
+ *   - a handle (bd_detector, bd_live) is used by one thread at a time, like the
+ *     reference's detectors (`Send`, not `Sync`: src/lib.rs:155);
+ *   - "device pointer" means memory of the GPU that is current for the call
+ *     (hipMalloc, or a torch CUDA tensor's data_ptr); `hip_stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream);
+ *   - there is no CPU fallback: without a usable GPU every compute call fails
+ *     with BD_ERR_NO_DEVICE / BD_ERR_HIP.
+ */
+#ifndef BEAT_DETECTOR_HIP_H
+#define BEAT_DETECTOR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BD_OK                 0
+#define BD_ERR_INVALID_ARG   -1
+#define BD_ERR_NO_DEVICE     -2
+#define BD_ERR_HIP           -3
+#define BD_ERR_UNSUPPORTED   -4
+#define BD_ERR_EMPTY_WINDOW  -5  /* the reference panics: window_stats.rs:51 */
+#define BD_ERR_NO_BINS       -6  /* the reference panics: spectrum.rs:88 unwrap */
+#define BD_ERR_STOPPED       -7  /* record.rs:45-47 keep_recording false */
+
+/* StrategyKind, src/lib.rs:144-149; numbering follows StrategyKind::values()
+ * (src/lib.rs:182-184) and the examples' menu
+ * (examples/audio_input_beat_detection.rs:95-99). */
+#define BD_KIND_LPF       0
+#define BD_KIND_SPECTRUM  1
+
+/* What `divide_by_N` divides by (third-party behaviour, not pinned by the
+ * reference): number of retained bins, FFT length, or nothing. */
+#define BD_DIV_BINS     0
+#define BD_DIV_FFT_LEN  1
+#define BD_DIV_NONE     2
+
+/* Constants of the path.  Defaults are the reference's hard-coded values; the
+ * spectrum_divisor / include_dc / inclusive / dc_packs_nyquist fields select
+ * among behaviours of the un-vendored spectrum-analyzer crate. */
+typedef struct bd_params {
+    uint32_t min_amplitude;      /* src/lib.rs:134 -> 9830 */
+    uint32_t min_beat_gap_ms;    /* spectrum.rs:126-131, lpf.rs:109-114 -> 400 */
+    float    spectrum_max_hz;    /* spectrum.rs:85 -> 90.0 */
+    float    spectrum_threshold; /* spectrum.rs:92 -> 2_100_000.0 (strict >) */
+    uint32_t spectrum_divisor;   /* BD_DIV_BINS */
+    uint32_t spectrum_include_dc;/* 1 */
+    uint32_t spectrum_inclusive; /* 1: keep bins with f <= max_hz */
+    uint32_t spectrum_dc_packs_nyquist; /* 0 */
+    uint32_t lpf_cutoff_hz;      /* lpf.rs:65 -> 120 */
+    float    lpf_ratio;          /* lpf.rs:74 -> 0.77 */
+} bd_params;
+
+void bd_default_params(bd_params *p);
+
+const char *bd_strerror(int status);
+const char *bd_last_error(void);
+
+/* Number of visible GPUs (0 and BD_OK when there is none). */
+int bd_device_count(int *count);
+
+/* ---- StrategyKind metadata ------------------------------------------- */
+/* StrategyKind::values().len(), src/lib.rs:182-184 */
+int bd_kind_count(void);
+/* StrategyKind::name / Strategy::name, src/lib.rs:164-170, spectrum.rs:106-111,
+ * lpf.rs:89-94.  NULL for an unknown kind. */
+const char *bd_kind_name(int kind);
+/* StrategyKind::description, src/lib.rs:173-179, spectrum.rs:113-120,
+ * lpf.rs:96-103 */
+const char *bd_kind_description(int kind);
+/* Strategy::min_duration_between_beats_ms, spectrum.rs:126-131, lpf.rs:109-114 */
+uint32_t bd_kind_min_duration_between_beats_ms(int kind);
+
+/* ---- per-window detector --------------------------------------------- */
+typedef struct bd_detector bd_detector;
+
+/* StrategyKind::detector(sampling_rate), src/lib.rs:155-161.
+ * params == NULL selects the defaults.  device < 0 selects the current device. */
+int bd_detector_create(int kind, uint32_t sampling_rate, const bd_params *params,
+                       int device, bd_detector **out);
+/* Strategy::is_beat(&self, samples: &[i16]) -> Option<BeatInfo>, src/lib.rs:78.
+ * `samples` is host memory, any n >= 1.  Returns 1 and stores
+ * BeatInfo::relative_ms (src/lib.rs:63-65) on a beat, 0 when there is none,
+ * BD_ERR_EMPTY_WINDOW for n == 0. */
+int bd_detector_is_beat(bd_detector *d, const int16_t *samples, size_t n,
+                        uint32_t *relative_ms);
+/* Strategy::kind, src/lib.rs:82 */
+int bd_detector_kind(const bd_detector *d);
+/* Diagnostics of the last call (no reference counterpart): the analysed value
+ * (Spectrum: scaled low-band maximum; LPF: max |y| after the filter) and the
+ * decision before the refractory rule. */
+int bd_detector_last(const bd_detector *d, float *value, int *candidate);
+void bd_detector_destroy(bd_detector *d);
+
+/* ---- batched offline analysis (new; thousands of streams per launch) --- */
+/* Equivalent to running, for every stream s independently, the harness loop
+ * of src/lib.rs:276-292: a fresh detector, then is_beat on consecutive
+ * callbacks of `callback_len` samples; a trailing partial callback is dropped. */
+
+/* callbacks per stream = n_samples / callback_len (src/lib.rs:276) */
+uint64_t bd_batch_callbacks(uint64_t n_samples, uint32_t callback_len);
+/* an upper bound on beats per stream for these arguments */
+uint32_t bd_batch_max_beats(uint32_t kind, uint32_t sampling_rate, const bd_params *params,
+                            uint64_t n_samples, uint32_t callback_len);
+
+/* All pointers are device pointers on the current device.
+ *   samples   [n_streams][stream_stride] i16, the first n_samples of each row used
+ *   values    [n_streams][n_callbacks] f32 or NULL   analysed value per callback
+ *   flags     [n_streams][n_callbacks] u8            decision before the refractory rule
+ *   beat_count[n_streams] u32                        beats found (may exceed max_beats)
+ *   beat_idx  [n_streams][max_beats] u32 or NULL     callback index of each beat
+ *   beat_ms   [n_streams][max_beats] u32 or NULL     BeatInfo::relative_ms of each beat
+ * The call only enqueues work on `hip_stream`; it allocates nothing and does
+ * not synchronise. */
+int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
+                     const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                     uint64_t stream_stride, uint32_t callback_len,
+                     float *values, uint8_t *flags,
+                     uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                     uint32_t max_beats, void *hip_stream);
+
+/* First stage of bd_analyze_batch alone: per-callback value and decision
+ * (amplitude gate + strategy decision, src/strategies/spectrum.rs:77-92 /
+ * lpf.rs:60-75), without the refractory rule.  Same pointer rules. */
+int bd_batch_candidates(int kind, uint32_t sampling_rate, const bd_params *params,
+                        const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                        uint64_t stream_stride, uint32_t callback_len,
+                        float *values, uint8_t *flags, void *hip_stream);
+
+/* Same analysis with every pointer in host memory; copies to `device`
+ * (< 0: current), runs, copies back and synchronises.  values/flags/beat_idx/
+ * beat_ms may be NULL. */
+int bd_analyze_batch_host(int kind, uint32_t sampling_rate, const bd_params *params,
+                          const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                          uint64_t stream_stride, uint32_t callback_len,
+                          float *values, uint8_t *flags,
+                          uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                          uint32_t max_beats, int device);
+
+/* Stream-sharded over several GPUs of one node: contiguous stream ranges, one
+ * host thread per device, no inter-GPU traffic.  Host pointers. */
+int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd_params *params,
+                           const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                           uint64_t stream_stride, uint32_t callback_len,
+                           float *values, uint8_t *flags,
+                           uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                           uint32_t max_beats, const int *devices, int n_devices);
+
+/* The refractory rule alone (Strategy::last_beat_beyond_threshold,
+ * src/lib.rs:115-127, with the clock of src/strategies/mod.rs:76-84) applied
+ * to per-callback decisions already on the device. */
+int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t callback_len,
+                  const uint8_t *flags, uint64_t n_streams, uint64_t n_callbacks,
+                  uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                  uint32_t max_beats, void *hip_stream);
+
+/* ---- ingest converters, src/record.rs:151-166 (device pointers) -------- */
+int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, void *hip_stream);
+int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, void *hip_stream);
+
+/* ---- deterministic synthetic click tracks (integer arithmetic only) ---- */
+/* Stream `first_stream + s` gets the same samples whatever batch it is
+ * generated in.  `samples` is a device pointer. */
+int bd_synth_fill(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                  uint64_t stream_stride, uint64_t first_stream, uint64_t seed,
+                  uint32_t sampling_rate, void *hip_stream);
+/* The same generator on the host (no GPU needed); bit-identical output. */
+int bd_synth_fill_host(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                       uint64_t stream_stride, uint64_t first_stream, uint64_t seed,
+                       uint32_t sampling_rate);
+
+/* ---- instrumentation --------------------------------------------------- */
+/* Name and grid of the dominant kernel of the last bd_analyze_batch call on
+ * this thread (for profilers). */
+const char *bd_last_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEAT_DETECTOR_HIP_H */

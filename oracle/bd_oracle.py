@@ -1,0 +1,236 @@
+"""ctypes binding of the CPU oracle (oracle/libbd_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by
+the cpu_baseline leg of bench.py -- never by the beat_detector_amd package.
+See bd_oracle.h for the pinning status of each restated function.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbd_oracle.so")
+
+KIND_LPF, KIND_SPECTRUM = 0, 1
+DIV_BINS, DIV_FFT_LEN, DIV_NONE = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("min_amplitude", C.c_uint32),
+        ("min_beat_gap_ms", C.c_uint32),
+        ("spectrum_max_hz", C.c_float),
+        ("spectrum_threshold", C.c_float),
+        ("spectrum_divisor", C.c_uint32),
+        ("spectrum_include_dc", C.c_uint32),
+        ("spectrum_inclusive", C.c_uint32),
+        ("spectrum_dc_packs_nyquist", C.c_uint32),
+        ("lpf_cutoff_hz", C.c_uint32),
+        ("lpf_ratio", C.c_float),
+    ]
+
+
+class State(C.Structure):
+    _fields_ = [
+        ("sampling_rate", C.c_uint32),
+        ("ms_per_sample", C.c_float),
+        ("beat_time_ms", C.c_uint32),
+        ("time_ms", C.c_uint32),
+        ("last_beat_timestamp", C.c_uint32),
+    ]
+
+
+class Detector(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int),
+        ("params", Params),
+        ("state", State),
+        ("ring", C.c_float * 1024),
+        ("ring_head", C.c_uint32),
+        ("last_value", C.c_float),
+        ("last_candidate", C.c_int),
+        ("last_computed", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, sz, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_float
+    L.bdo_default_params.argtypes = [C.POINTER(Params)]
+    L.bdo_state_new.argtypes = [C.POINTER(State), u32]
+    L.bdo_state_update_time.argtypes = [C.POINTER(State), sz]
+    L.bdo_state_mark_beat.argtypes = [C.POINTER(State)]
+    L.bdo_last_beat_beyond_threshold.argtypes = [C.POINTER(State), u32]
+    L.bdo_amplitude_high_enough.argtypes = [C.c_uint16, u32]
+    L.bdo_window_max.argtypes = [vp, sz]
+    L.bdo_window_max.restype = C.c_uint16
+    L.bdo_apply_lpf_i16_sp.argtypes = [vp, sz, C.c_uint16, C.c_uint16]
+    L.bdo_apply_lpf_i16_sp.restype = None
+    L.bdo_spectrum_band_max.argtypes = [vp, u32, C.POINTER(Params), C.POINTER(C.c_int)]
+    L.bdo_spectrum_band_max.restype = f32
+    L.bdo_spectrum_band_max_f64.argtypes = [vp, u32, C.POINTER(Params)]
+    L.bdo_spectrum_band_max_f64.restype = C.c_double
+    L.bdo_spectrum_bin_range.argtypes = [u32, C.POINTER(Params), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.bdo_detector_new.argtypes = [C.POINTER(Detector), C.c_int, u32, C.POINTER(Params)]
+    L.bdo_is_beat.argtypes = [C.POINTER(Detector), vp, sz, C.POINTER(u32)]
+    L.bdo_is_beat_full.argtypes = [C.POINTER(Detector), vp, sz, C.POINTER(u32)]
+    L.bdo_u16_data_to_i16.argtypes = [vp, vp, sz]
+    L.bdo_f32_data_to_i16.argtypes = [vp, vp, sz]
+    L.bdo_stereo_to_mono.argtypes = [vp, sz, vp]
+    L.bdo_harness_padded_len.argtypes = [sz, sz]
+    L.bdo_harness_padded_len.restype = sz
+    L.bdo_run_stream.argtypes = [C.c_int, u32, C.POINTER(Params), vp, sz, sz, C.c_int, vp, vp, vp, vp, sz]
+    L.bdo_run_stream.restype = sz
+    L.bdo_run_batch.argtypes = [C.c_int, u32, C.POINTER(Params), vp, sz, sz, sz, sz, C.c_int, vp]
+    L.bdo_run_batch.restype = u64
+    _lib = L
+    return L
+
+
+def default_params(**overrides) -> Params:
+    p = Params()
+    lib().bdo_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _vp(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def window_max(samples) -> int:
+    a = np.ascontiguousarray(samples, dtype=np.int16)
+    return int(lib().bdo_window_max(_vp(a), a.size))
+
+
+def apply_lpf(samples, sample_rate_hz: int, cutoff_hz: int) -> np.ndarray:
+    a = np.array(samples, dtype=np.int16, copy=True)
+    lib().bdo_apply_lpf_i16_sp(_vp(a), a.size, sample_rate_hz & 0xFFFF, cutoff_hz & 0xFFFF)
+    return a
+
+
+def spectrum_band_max(ring, sampling_rate: int, params: Params | None = None):
+    r = np.ascontiguousarray(ring, dtype=np.float32)
+    assert r.size == 1024
+    p = params if params is not None else default_params()
+    nb = C.c_int(0)
+    v = lib().bdo_spectrum_band_max(_vp(r), sampling_rate, C.byref(p), C.byref(nb))
+    return float(v), nb.value
+
+
+def spectrum_band_max_f64(ring, sampling_rate: int, params: Params | None = None) -> float:
+    r = np.ascontiguousarray(ring, dtype=np.float32)
+    p = params if params is not None else default_params()
+    return float(lib().bdo_spectrum_band_max_f64(_vp(r), sampling_rate, C.byref(p)))
+
+
+def bin_range(sampling_rate: int, params: Params | None = None):
+    p = params if params is not None else default_params()
+    a, b = C.c_int(0), C.c_int(0)
+    n = lib().bdo_spectrum_bin_range(sampling_rate, C.byref(p), C.byref(a), C.byref(b))
+    return n, a.value, b.value
+
+
+class OracleDetector:
+    """A reference detector (StrategyKind::detector + Strategy::is_beat)."""
+
+    def __init__(self, kind: int, sampling_rate: int, params: Params | None = None):
+        self.d = Detector()
+        rc = lib().bdo_detector_new(C.byref(self.d), kind, sampling_rate, C.byref(params) if params is not None else None)
+        if rc != 0:
+            raise ValueError("unknown kind")
+
+    def is_beat(self, samples, full: bool = False):
+        a = np.ascontiguousarray(samples, dtype=np.int16)
+        ms = C.c_uint32(0)
+        fn = lib().bdo_is_beat_full if full else lib().bdo_is_beat
+        r = fn(C.byref(self.d), _vp(a), a.size, C.byref(ms))
+        if r < 0:
+            raise ValueError("empty window: the reference panics")
+        return ms.value if r == 1 else None
+
+    @property
+    def last_value(self) -> float:
+        return float(self.d.last_value)
+
+    @property
+    def last_candidate(self) -> bool:
+        return bool(self.d.last_candidate)
+
+    @property
+    def state(self) -> State:
+        return self.d.state
+
+
+def run_stream(kind: int, sampling_rate: int, samples, callback_len: int, params: Params | None = None,
+               full: bool = True, max_beats: int | None = None):
+    """Returns (values f32[n_cb], candidates u8[n_cb], [(callback index, ms)])."""
+    a = np.ascontiguousarray(samples, dtype=np.int16)
+    n_cb = a.size // callback_len
+    if max_beats is None:
+        max_beats = max(n_cb, 1)
+    values = np.zeros(n_cb, dtype=np.float32)
+    cands = np.zeros(n_cb, dtype=np.uint8)
+    idx = np.zeros(max_beats, dtype=np.uint32)
+    ms = np.zeros(max_beats, dtype=np.uint32)
+    p = params if params is not None else default_params()
+    n = lib().bdo_run_stream(kind, sampling_rate, C.byref(p), _vp(a), a.size, callback_len, 1 if full else 0,
+                             _vp(values), _vp(cands), _vp(idx), _vp(ms), max_beats)
+    n = min(int(n), max_beats)
+    return values, cands, list(zip(idx[:n].astype(np.int64).tolist(), ms[:n].astype(np.int64).tolist()))
+
+
+def run_batch(kind: int, sampling_rate: int, samples2d, callback_len: int, params: Params | None = None,
+              n_threads: int = 1):
+    a = np.ascontiguousarray(samples2d, dtype=np.int16)
+    n_streams, n = a.shape
+    counts = np.zeros(n_streams, dtype=np.uint32)
+    p = params if params is not None else default_params()
+    total = lib().bdo_run_batch(kind, sampling_rate, C.byref(p), _vp(a), n_streams, n, n, callback_len, n_threads,
+                                _vp(counts))
+    return int(total), counts
+
+
+def u16_data_to_i16(data) -> np.ndarray:
+    a = np.ascontiguousarray(data, dtype=np.uint16)
+    out = np.zeros(a.shape, dtype=np.int16)
+    lib().bdo_u16_data_to_i16(_vp(a), _vp(out), a.size)
+    return out
+
+
+def f32_data_to_i16(data) -> np.ndarray:
+    a = np.ascontiguousarray(data, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.int16)
+    lib().bdo_f32_data_to_i16(_vp(a), _vp(out), a.size)
+    return out
+
+
+def stereo_to_mono(interleaved) -> np.ndarray:
+    a = np.ascontiguousarray(interleaved, dtype=np.int16)
+    n = a.size // 2
+    out = np.zeros(n, dtype=np.int16)
+    lib().bdo_stereo_to_mono(_vp(a), n, _vp(out))
+    return out
+
+
+def harness_padded_len(n: int, window_len: int) -> int:
+    return int(lib().bdo_harness_padded_len(n, window_len))

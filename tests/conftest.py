@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # A gpu-marked test on a machine without a GPU is skipped rather than failed,
+    # so that a plain `pytest tests/` works in the CPU container.
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import bd_oracle
+    bd_oracle.lib()
+    return bd_oracle
+
+
+@pytest.fixture(scope="session")
+def bd():
+    import beat_detector_amd
+    beat_detector_amd.lib()
+    return beat_detector_amd

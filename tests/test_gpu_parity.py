@@ -1,0 +1,320 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle on the same
+inputs.  Integer results (decisions, beat indices, beat times, LPF values,
+converters, generator) are compared bit-exactly; Spectrum band values within
+1e-4 relative (see util.value_tolerance)."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+SR = 44100
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _run_gpu(bd, kind, sr, x, L, params=None):
+    torch = _torch()
+    n_streams, n = x.shape
+    stride = (n + 7) & ~7
+    buf = torch.zeros((n_streams, stride), dtype=torch.int16, device="cuda")
+    buf[:, :n] = torch.from_numpy(x).cuda()
+    res = bd.analyze_batch(kind, sr, buf, L, n_samples=n, params=params)
+    torch.cuda.synchronize()
+    return res
+
+
+def _compare(bd, oracle, kind_name, sr, x, L, bd_params=None, o_params=None, exact_values=False):
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    res = _run_gpu(bd, kind, sr, x, L, bd_params)
+    ref_v, ref_c, ref_b = util.oracle_batch(oracle, okind, sr, x, L, o_params)
+    got_v = res.values.cpu().numpy()
+    got_c = res.flags.cpu().numpy()
+    assert got_v.shape == ref_v.shape
+    if exact_values:
+        np.testing.assert_array_equal(got_v, ref_v)
+        adjacent = np.zeros_like(ref_c, dtype=bool)
+    else:
+        p = o_params if o_params is not None else oracle.default_params()
+        nb, _, _ = oracle.bin_range(sr, p)
+        div = {0: nb, 1: 1024, 2: 0}[p.spectrum_divisor]
+        tol = util.value_tolerance(ref_v, np.abs(x.astype(np.int32)).max(), div)
+        bad = np.abs(got_v.astype(np.float64) - ref_v) > tol
+        assert not bad.any(), f"{bad.sum()} band values off; worst {np.abs(got_v - ref_v).max()}"
+        adjacent = util.threshold_adjacent(ref_v, p.spectrum_threshold)
+    mism = (got_c != ref_c)
+    assert not (mism & ~adjacent).any(), f"decisions differ at {np.argwhere(mism & ~adjacent)[:10]}"
+    if not mism.any():
+        # beat lists must then be identical: index and relative_ms
+        for s in range(x.shape[0]):
+            assert res.beats(s) == ref_b[s], f"stream {s}"
+    else:
+        print("threshold-adjacent callbacks with flipped decision:", np.argwhere(mism).tolist())
+    return res, ref_v, ref_c, ref_b
+
+
+def _synth(bd, n_streams, n, first=0, seed=0x5EED, sr=SR):
+    return bd.synth_fill_host(n_streams, n, first_stream=first, seed=seed, sampling_rate=sr)
+
+
+@pytest.mark.parametrize("L", [512, 1024])
+def test_spectrum_fast_path(bd, oracle, L):
+    x = _synth(bd, 6, SR * 12)
+    res, ref_v, ref_c, ref_b = _compare(bd, oracle, "Spectrum", SR, x, L)
+    assert bd.last_kernel_name() == "bd_spectrum_band_kernel"
+    assert ref_c.sum() > 0 and sum(len(b) for b in ref_b) > 0   # the case exercises beats
+    assert (ref_c == 0).sum() > 0
+
+
+def test_spectrum_ragged_lengths(bd, oracle):
+    # lengths that are not multiples of the callback, of a half-block run, or of 8
+    for n in (511, 512, 1023, 1024, 1537, 4096 + 3, 512 * 129 + 5, 1024 * 67 + 1001):
+        x = _synth(bd, 3, n, first=11)
+        for L in (512, 1024):
+            _compare(bd, oracle, "Spectrum", SR, x, L)
+
+
+@pytest.mark.parametrize("L", [1, 7, 64, 317, 529, 700, 1500, 2048, 3000])
+def test_spectrum_generic_callback_lengths(bd, oracle, L):
+    x = _synth(bd, 2, 40000, first=3)
+    _compare(bd, oracle, "Spectrum", SR, x, L)
+    assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+
+
+@pytest.mark.parametrize("sr", [8000, 16000, 22050, 48000, 96000, 192000])
+def test_spectrum_other_sampling_rates(bd, oracle, sr):
+    x = _synth(bd, 2, 60000, first=5, sr=sr)
+    for L in (512, 1024, 600):
+        _compare(bd, oracle, "Spectrum", sr, x, L)
+
+
+def test_spectrum_unpinned_choices(bd, oracle):
+    """Every documented choice for the third-party behaviour is implemented the
+    same way on both sides."""
+    x = _synth(bd, 2, SR * 4, first=21)
+    combos = [
+        dict(spectrum_divisor=1), dict(spectrum_divisor=2), dict(spectrum_include_dc=0),
+        dict(spectrum_inclusive=0), dict(spectrum_dc_packs_nyquist=1),
+        dict(spectrum_divisor=2, spectrum_threshold=3.0e6, spectrum_dc_packs_nyquist=1),
+        dict(spectrum_max_hz=43.06640625), dict(spectrum_max_hz=43.06640625, spectrum_inclusive=0),
+    ]
+    for c in combos:
+        for L in (512, 1024, 333):
+            _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**c), oracle.default_params(**c))
+
+
+def test_spectrum_edge_signals(bd, oracle):
+    n = 1024 * 24
+    rows = [
+        np.zeros(n, dtype=np.int16),                                   # silence
+        np.full(n, -32768, dtype=np.int16),                            # i16::MIN everywhere (DC = -2^25)
+        np.full(n, 32767, dtype=np.int16),
+        np.tile(np.array([32767, -32768], dtype=np.int16), n // 2),    # Nyquist tone
+        (20000 * np.sin(2 * np.pi * 43.06640625 * np.arange(n) / SR)).astype(np.int16),  # exactly bin 1
+        (30000 * np.sin(2 * np.pi * 86.1328125 * np.arange(n) / SR)).astype(np.int16),   # exactly bin 2
+        np.where(np.arange(n) % 1024 == 1023, 9829, 0).astype(np.int16),  # just below the amplitude gate
+        np.where(np.arange(n) % 1024 == 1023, -9830, 0).astype(np.int16), # exactly at the gate
+    ]
+    x = np.stack(rows)
+    for L in (512, 1024):
+        for c in (dict(), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_threshold=1000.0)):
+            _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**c), oracle.default_params(**c))
+
+
+@pytest.mark.parametrize("L", [1024, 512, 2048, 64, 8])
+def test_lpf_aligned(bd, oracle, L):
+    x = _synth(bd, 5, SR * 8)
+    res, ref_v, ref_c, ref_b = _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+    assert bd.last_kernel_name() == "bd_lpf_window_kernel"
+    if L >= 512:
+        assert ref_c.sum() > 0
+
+
+@pytest.mark.parametrize("L", [1, 3, 317, 529, 1000, 1023, 1025, 4100])
+def test_lpf_ragged(bd, oracle, L):
+    x = _synth(bd, 3, 50000 + L, first=9)
+    _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+
+
+def test_lpf_many_windows_per_stream(bd, oracle):
+    # more than 64 windows per stream, not a multiple of 64; odd stream count
+    x = _synth(bd, 7, 1024 * 131 + 77, first=100)
+    _compare(bd, oracle, "LPF", SR, x, 1024, exact_values=True)
+
+
+@pytest.mark.parametrize("sr", [8000, 48000, 65535, 65536, 88200, 96000])
+def test_lpf_sampling_rate_wraps_as_u16(bd, oracle, sr):
+    # lpf.rs:69 passes `sampling_rate as u16`: 88200 -> 22664, 96000 -> 30464, 65536 -> 0
+    x = _synth(bd, 2, 60000, first=2, sr=sr)
+    _compare(bd, oracle, "LPF", sr, x, 1024, exact_values=True)
+
+
+def test_lpf_edge_signals_and_params(bd, oracle):
+    n = 1024 * 20
+    rows = [
+        np.zeros(n, dtype=np.int16),
+        np.full(n, -32768, dtype=np.int16),
+        np.full(n, 32767, dtype=np.int16),
+        np.tile(np.array([32767, -32768], dtype=np.int16), n // 2),
+        np.where(np.arange(n) % 1024 < 700, 9830, 0).astype(np.int16),
+        np.where(np.arange(n) % 1024 < 700, 9829, 0).astype(np.int16),
+        (25000 * np.sin(2 * np.pi * 50 * np.arange(n) / SR)).astype(np.int16),
+    ]
+    x = np.stack(rows)
+    for c in (dict(), dict(lpf_cutoff_hz=4000), dict(lpf_ratio=0.2), dict(lpf_ratio=1.5), dict(lpf_cutoff_hz=0),
+              dict(min_amplitude=0, lpf_ratio=0.0)):
+        _compare(bd, oracle, "LPF", SR, x, 1024, bd.Params.default(**c), oracle.default_params(**c), exact_values=True)
+
+
+def test_refractory_rule_dense_decisions(bd, oracle):
+    """All-ones and random decision vectors through bd_refractory against a
+    literal replay of the reference's clock + gate."""
+    import ctypes as C
+    torch = _torch()
+    rng = np.random.default_rng(5)
+    for sr, L in ((44100, 1024), (44100, 512), (48000, 480), (8000, 4000), (44100, 1), (96000, 20000)):
+        n_cb = 700
+        flags = np.stack([np.ones(n_cb, np.uint8), np.zeros(n_cb, np.uint8),
+                          (rng.random(n_cb) < 0.3).astype(np.uint8), (rng.random(n_cb) < 0.02).astype(np.uint8)])
+        count, idx, ms = bd.refractory(sr, L, torch.from_numpy(flags).cuda(), max_beats=n_cb)
+        torch.cuda.synchronize()
+        count, idx, ms = count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()
+        Lo = oracle.lib()
+        for s in range(flags.shape[0]):
+            st = oracle.State()
+            Lo.bdo_state_new(C.byref(st), sr)
+            want = []
+            for j in range(n_cb):
+                Lo.bdo_state_update_time(C.byref(st), L)
+                if Lo.bdo_last_beat_beyond_threshold(C.byref(st), 400) and flags[s, j]:
+                    Lo.bdo_state_mark_beat(C.byref(st))
+                    want.append((j, st.beat_time_ms))
+            got = list(zip(idx[s, :count[s]].tolist(), ms[s, :count[s]].tolist()))
+            assert got == want, (sr, L, s)
+
+
+def test_beat_list_capacity_is_reported_not_overrun(bd):
+    torch = _torch()
+    flags = torch.ones((3, 500), dtype=torch.uint8, device="cuda")
+    count, idx, ms = bd.refractory(44100, 1024, flags, max_beats=4)
+    torch.cuda.synchronize()
+    assert (count.cpu().numpy() > 4).all()      # true number of beats
+    assert idx.shape == (3, 4)
+
+
+@pytest.mark.parametrize("kind_name", ["LPF", "Spectrum"])
+@pytest.mark.parametrize("L", [1024, 512, 529])
+def test_detector_handle_matches_reference_call_by_call(bd, oracle, kind_name, L):
+    """StrategyKind::detector + Strategy::is_beat, callback by callback."""
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    x = _synth(bd, 1, SR * 5, first=4)[0]
+    det = kind.detector(SR)
+    ref = oracle.OracleDetector(okind, SR)
+    assert det.kind() == kind
+    n_beats = 0
+    for j in range(len(x) // L):
+        w = x[j * L:(j + 1) * L]
+        got = det.is_beat(w)
+        want = ref.is_beat(w)
+        assert (got.relative_ms() if got else None) == want, f"callback {j}"
+        n_beats += want is not None
+    assert n_beats > 0
+    det.close()
+
+
+def test_detector_handle_variable_callback_lengths(bd, oracle):
+    # Linux callbacks: "mostly 500-540" samples (spectrum.rs:40-42)
+    rng = np.random.default_rng(3)
+    x = _synth(bd, 1, SR * 6, first=8)[0]
+    for kind_name in ("LPF", "Spectrum"):
+        kind = bd.StrategyKind[kind_name]
+        okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+        det, ref = kind.detector(SR), oracle.OracleDetector(okind, SR)
+        pos = 0
+        while pos < len(x) - 3000:
+            n = int(rng.choice([500, 512, 529, 540, 1, 1024, 2500]))
+            w = x[pos:pos + n]
+            got, want = det.is_beat(w), ref.is_beat(w)
+            assert (got.relative_ms() if got else None) == want
+            pos += n
+        det.close()
+
+
+def test_detector_empty_window_is_an_error(bd):
+    det = bd.StrategyKind.Spectrum.detector(SR)
+    with pytest.raises(bd.BeatDetectorError) as e:
+        det.is_beat(np.zeros(0, dtype=np.int16))
+    assert e.value.status == -5
+    det.close()
+
+
+def test_converters_match_reference(bd, oracle):
+    torch = _torch()
+    u = np.arange(65536, dtype=np.uint16)
+    got = bd.u16_data_to_i16(torch.from_numpy(u.view(np.int16)).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.u16_data_to_i16(u))
+    rng = np.random.default_rng(0)
+    f = np.concatenate([rng.uniform(-1.2, 1.2, 100000).astype(np.float32),
+                        np.array([0, 1, -1, np.nan, np.inf, -np.inf, 1e-8, -1e-8, 0.99999, 3.0e9], dtype=np.float32)])
+    got = bd.f32_data_to_i16(torch.from_numpy(f).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.f32_data_to_i16(f))
+
+
+def test_generator_device_equals_host(bd):
+    torch = _torch()
+    for n_streams, n, first in ((5, 44100 * 3 + 5, 0), (3, 1000, 77), (2, 8, 5), (1, 7, 2)):
+        stride = (n + 7) & ~7
+        buf = torch.zeros((n_streams, stride), dtype=torch.int16, device="cuda")
+        bd.synth_fill(buf, n_samples=n, first_stream=first, seed=1234)
+        torch.cuda.synchronize()
+        host = bd.synth_fill_host(n_streams, n, first_stream=first, seed=1234)
+        np.testing.assert_array_equal(buf[:, :n].cpu().numpy(), host)
+
+
+def test_host_pointer_entry_points(bd, oracle):
+    x = _synth(bd, 9, SR * 3, first=30)
+    for kind_name in ("LPF", "Spectrum"):
+        kind = bd.StrategyKind[kind_name]
+        okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+        _, ref_c, ref_b = util.oracle_batch(oracle, okind, SR, x, 1024)
+        for res in (bd.analyze_batch_host(kind, SR, x, 1024), bd.analyze_batch_multi(kind, SR, x, 1024, devices=[0])):
+            np.testing.assert_array_equal(res.flags, ref_c)
+            for s in range(x.shape[0]):
+                assert res.beats(s) == ref_b[s]
+
+
+def test_full_size_properties_spectrum(bd):
+    """At a size the oracle cannot finish: size-independent properties.
+    (a) a stream's results do not depend on which batch it is analysed in;
+    (b) decisions are invariant under sign inversion of the samples (|X| and
+        max|x| are even), values agree within tolerance;
+    (c) hop-512 callbacks with odd index see the same ring as 1024-callbacks:
+        values[2j+1] at L=512 equals values[j] at L=1024."""
+    torch = _torch()
+    n_streams, n = 512, SR * 60
+    stride = (n + 7) & ~7
+    buf = torch.zeros((n_streams, stride), dtype=torch.int16, device="cuda")
+    bd.synth_fill(buf, n_samples=n, seed=99)
+    K = bd.StrategyKind.Spectrum
+    full = bd.analyze_batch(K, SR, buf, 512, n_samples=n)
+    sub = bd.analyze_batch(K, SR, buf[100:117].contiguous(), 512, n_samples=n)
+    torch.cuda.synchronize()
+    assert torch.equal(full.flags[100:117], sub.flags)
+    assert torch.equal(full.beat_count[100:117], sub.beat_count)
+    assert torch.equal(full.beat_ms[100:117], sub.beat_ms)
+    neg = bd.analyze_batch(K, SR, torch.clamp(-buf.to(torch.int32), -32768, 32767).to(torch.int16), 512, n_samples=n)
+    torch.cuda.synchronize()
+    close = torch.isclose(neg.values, full.values, rtol=1e-5, atol=1.0)
+    assert close.all()
+    assert (neg.flags != full.flags).sum().item() <= 2
+    l1024 = bd.analyze_batch(K, SR, buf, 1024, n_samples=n)
+    torch.cuda.synchronize()
+    n2 = l1024.values.shape[1]
+    assert torch.isclose(full.values[:, 1:2 * n2:2], l1024.values, rtol=1e-5, atol=1.0).all()
+    assert int(full.beat_count.sum()) > 0
