@@ -194,8 +194,9 @@ extern "C" uint32_t bd_batch_max_beats(uint32_t kind, uint32_t sampling_rate, co
 static int bd_check_batch_args(const int16_t *samples, uint64_t n_samples, uint64_t stride,
                                uint32_t callback_len, const uint8_t *flags)
 {
-    if (!samples || !flags) { bd_set_error("samples and flags must not be NULL"); return BD_ERR_INVALID_ARG; }
     if (callback_len == 0) { bd_set_error("callback_len must be >= 1 (the reference panics on an empty window)"); return BD_ERR_EMPTY_WINDOW; }
+    // with no complete callback there is nothing to read or write
+    if ((!samples || !flags) && n_samples / callback_len > 0) { bd_set_error("samples and flags must not be NULL"); return BD_ERR_INVALID_ARG; }
     if (stride < n_samples) { bd_set_error("stream_stride (%llu) < n_samples (%llu)", (unsigned long long)stride, (unsigned long long)n_samples); return BD_ERR_INVALID_ARG; }
     return BD_OK;
 }
