@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched per-window analysis path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path (per-callback decisions + refractory pass ->
+beat lists) over one batch of synthetic streams that is already resident in
+HBM.  Default workload: the Spectrum strategy on 16,384 streams x 60 s at
+44.1 kHz, 512-sample callbacks (1024-point analysis window, hop 512).  With N
+GPUs every rank analyses its own 16,384 streams (weak scaling, no collective on
+the data path); the reported value is the audio-seconds all ranks analysed per
+wall-second, timed between barriers, maximum over ranks.
+
+Rank 0 prints one JSON line.  `roofline` prices the dominant kernel against HBM
+bandwidth using HIP events recorded inside the timed region; `cpu_baseline` is
+the CPU restatement of the reference (oracle/) timed on this host's cores on a
+bounded sample of the same streams (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+
+WORKLOADS = {
+    # name: (kind, callback_len, streams, seconds, description)
+    "spectrum_hop512": ("Spectrum", 512, 16384, 60,
+                        "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, "
+                        "1024-pt window hop 512 (512-sample callbacks), low-band max + threshold + refractory"),
+    "spectrum_1024": ("Spectrum", 1024, 16384, 60,
+                      "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, "
+                      "1024-sample non-overlapping callbacks"),
+    "lpf": ("LPF", 1024, 4096, 60,
+            "LPF strategy batched: 4,096 synthetic click-track streams x 60 s @ 44.1 kHz, 1024-sample windows"),
+}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="spectrum_hop512", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (testing only)")
+    ap.add_argument("--seconds", type=int, default=0, help="override stream length in seconds (testing only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams in the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import beat_detector_amd as bd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kind_name, L, streams, seconds, desc = WORKLOADS[args.workload]
+    if args.streams:
+        streams = args.streams
+    if args.seconds:
+        seconds = args.seconds
+    kind = bd.StrategyKind[kind_name]
+    sr = 44100
+    n = sr * seconds
+    stride = (n + 7) & ~7
+    seed = 0x5EED
+    first_stream = rank * streams  # every rank analyses different streams
+
+    samples = torch.empty((streams, stride), dtype=torch.int16, device=dev)
+    bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=seed, sampling_rate=sr)
+    n_cb = n // L
+    max_beats = max(1, bd.batch_max_beats(kind, sr, n, L))
+    values = torch.empty((streams, n_cb), dtype=torch.float32, device=dev)
+    flags = torch.empty((streams, n_cb), dtype=torch.uint8, device=dev)
+    count = torch.zeros((streams,), dtype=torch.int32, device=dev)
+    idx = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
+    ms = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    L_ = bd.lib()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def stage1():
+        rc = L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
+                                    values.data_ptr(), flags.data_ptr(), st)
+        if rc != 0:
+            raise RuntimeError(L_.bd_last_error().decode())
+
+    def stage2():
+        rc = L_.bd_refractory(sr, None, L, flags.data_ptr(), streams, n_cb, count.data_ptr(), idx.data_ptr(),
+                              ms.data_ptr(), max_beats, st)
+        if rc != 0:
+            raise RuntimeError(L_.bd_last_error().decode())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stage1()
+        stage2()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        stage1()                      # dominant kernel
+        ev[k][1].record()
+        stage2()                      # refractory pass
+        ev[k][2].record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    kernel_name = "bd_spectrum_band_kernel" if kind_name == "Spectrum" else "bd_lpf_window_kernel"
+    total_beats = int(count.sum().item())
+
+    if dist is not None:
+        t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, k1_ms = float(t[0]), float(t[1])
+        tb = torch.tensor([total_beats], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb)
+        total_beats = int(tb[0])
+
+    audio_sec_per_step = world * streams * (n / sr)
+    value = audio_sec_per_step * args.steps / elapsed
+    # algorithmic bytes of one launch of the dominant kernel: every sample that
+    # belongs to a callback read once (2 B) + 5 B written per callback
+    alg_bytes = streams * (n_cb * L * 2 + n_cb * 5)
+    achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+
+    result = {
+        "metric": "audio-sec analysed/sec (node), 1024-pt STFT",
+        "value": value,
+        "unit": "audio-sec/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": desc,
+            "strategy": kind_name,
+            "streams_per_gpu": streams,
+            "seconds_per_stream": seconds,
+            "sampling_rate": sr,
+            "callback_len": L,
+            "callbacks_per_stream": n_cb,
+            "seed": seed,
+            "parallelism": f"stream-sharded x{world}, no collectives",
+            "beats_found": total_beats,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": kernel_name,
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": _pmc_traffic(args.workload, streams, seconds),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": k1_ms,
+            "refractory_ms": k2_ms,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(bd, kind_name, samples, n, L, sr, min(args.cpu_streams, streams))
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(workload, streams, seconds):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    PMC passes of this same command (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t.get(workload)
+        if e and e.get("streams") == streams and e.get("seconds") == seconds:
+            return e.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams):
+    """The CPU restatement of the reference (oracle/, a port: the Rust original
+    cannot be built here) on the first `n_streams` streams of the same batch."""
+    from oracle import bd_oracle
+    okind = bd_oracle.KIND_SPECTRUM if kind_name == "Spectrum" else bd_oracle.KIND_LPF
+    host = samples[:n_streams, :n].cpu().numpy()
+    cores = 16
+    try:
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    total, _ = bd_oracle.run_batch(okind, sr, host, L, n_threads=cores)
+    dt = time.perf_counter() - t0
+    one = max(1, n_streams // (cores * 2))
+    t1 = time.perf_counter()
+    bd_oracle.run_batch(okind, sr, host[:one], L, n_threads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": n_streams * (n / sr) / dt,
+        "unit": "audio-sec/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_streams} streams x {n // sr} s of the same batch, {cores} threads "
+                  f"(one contiguous stream shard each), {dt:.1f} s of wall time; beats found {total}",
+        "value_1core": one * (n / sr) / dt1,
+        "sample_1core": f"first {one} streams, 1 thread, {dt1:.1f} s",
+    }
+
+
+if __name__ == "__main__":
+    main()
