@@ -101,11 +101,11 @@ def lib() -> C.CDLL:
         "bd_detector_destroy": (None, [vp]),
         "bd_batch_callbacks": (u64, [u64, u32]),
         "bd_batch_max_beats": (u32, [u32, u32, pp, u64, u32]),
-        "bd_analyze_batch": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, vp]),
-        "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp]),
+        "bd_analyze_batch": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp]),
         "bd_analyze_batch_host": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, i32]),
         "bd_analyze_batch_multi": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, C.POINTER(i32), i32]),
-        "bd_refractory": (i32, [u32, pp, u32, vp, u64, u64, vp, vp, vp, u32, vp]),
+        "bd_refractory": (i32, [u32, pp, u32, vp, u64, u64, u64, vp, vp, vp, u32, vp]),
         "bd_u16_data_to_i16": (i32, [vp, vp, u64, vp]),
         "bd_f32_data_to_i16": (i32, [vp, vp, u64, vp]),
         "bd_synth_fill": (i32, [vp, u64, u64, u64, u64, u64, u32, vp]),
@@ -268,6 +268,24 @@ def _require_cuda(t, dtype, name):
         raise BeatDetectorError(BD_ERR_INVALID_ARG, f"{name} must be a contiguous CUDA tensor of {dtype}")
 
 
+def _out_rows(n_streams: int, n_cb: int, dtype, device):
+    """[n_streams, n_cb] view of rows padded to a multiple of 128 entries, so
+    that every row starts on a 128-byte boundary (full-line stores)."""
+    pitch = max(128, (n_cb + 127) & ~127)
+    return torch.empty((n_streams, pitch), dtype=dtype, device=device)[:, :n_cb]
+
+
+def _row_stride(flags, values=None) -> int:
+    """Row pitch (in callbacks) shared by the flags and values tensors."""
+    for t in (flags, values):
+        if t is not None and (t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1)):
+            raise BeatDetectorError(BD_ERR_INVALID_ARG, "outputs must be 2-D with unit inner stride")
+    fs = flags.stride(0) if flags.shape[0] > 1 else max(flags.shape[1], 1)
+    if values is not None and values.shape[0] > 1 and values.stride(0) != fs:
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "values and flags must have the same row pitch")
+    return fs
+
+
 def batch_candidates(kind: StrategyKind, sampling_rate: int, samples, callback_len: int,
                      n_samples: Optional[int] = None, params: Optional[Params] = None,
                      want_values: bool = True, values=None, flags=None, stream=None):
@@ -278,26 +296,29 @@ def batch_candidates(kind: StrategyKind, sampling_rate: int, samples, callback_l
     n = stride if n_samples is None else n_samples
     n_cb = n // callback_len if callback_len else 0
     if flags is None:
-        flags = torch.empty((n_streams, n_cb), dtype=torch.uint8, device=samples.device)
+        flags = _out_rows(n_streams, n_cb, torch.uint8, samples.device)
     if values is None and want_values:
-        values = torch.empty((n_streams, n_cb), dtype=torch.float32, device=samples.device)
+        values = _out_rows(n_streams, n_cb, torch.float32, samples.device)
+    out_stride = _row_stride(flags, values)
     with torch.cuda.device(samples.device):
         _check(lib().bd_batch_candidates(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams, n,
-                                         stride, callback_len, _dev_ptr(values), flags.data_ptr(),
+                                         stride, callback_len, _dev_ptr(values), flags.data_ptr(), out_stride,
                                          _stream_ptr(stream)))
     return values, flags
 
 
 def refractory(sampling_rate: int, callback_len: int, flags, max_beats: int, params: Optional[Params] = None,
                stream=None):
-    _require_cuda(flags, torch.uint8, "flags")
+    if not (isinstance(flags, torch.Tensor) and flags.is_cuda and flags.dtype == torch.uint8):
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "flags must be a CUDA uint8 tensor")
     n_streams, n_cb = flags.shape
     dev = flags.device
     count = torch.empty((n_streams,), dtype=torch.int32, device=dev)
     idx = torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev)
     ms = torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        _check(lib().bd_refractory(sampling_rate, _pp(params), callback_len, flags.data_ptr(), n_streams, n_cb,
+        _check(lib().bd_refractory(sampling_rate, _pp(params), callback_len, flags.data_ptr(), _row_stride(flags),
+                                   n_streams, n_cb,
                                    count.data_ptr(), idx.data_ptr(), ms.data_ptr(), max_beats, _stream_ptr(stream)))
     return count, idx, ms
 
@@ -333,8 +354,8 @@ def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len:
         max_beats = max(1, batch_max_beats(kind, sampling_rate, n, callback_len, params)) if callback_len else 1
     if out is None:
         out = BatchResult(
-            torch.empty((n_streams, n_cb), dtype=torch.float32, device=dev) if want_values else None,
-            torch.empty((n_streams, n_cb), dtype=torch.uint8, device=dev),
+            _out_rows(n_streams, n_cb, torch.float32, dev) if want_values else None,
+            _out_rows(n_streams, n_cb, torch.uint8, dev),
             torch.zeros((n_streams,), dtype=torch.int32, device=dev),
             torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
             torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
@@ -342,7 +363,7 @@ def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len:
     with torch.cuda.device(dev):
         _check(lib().bd_analyze_batch(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams, n, stride,
                                       callback_len, _dev_ptr(out.values), out.flags.data_ptr(),
-                                      out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
+                                      _row_stride(out.flags, out.values), out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
                                       out.beat_idx.shape[1], _stream_ptr(stream)))
     return out
 

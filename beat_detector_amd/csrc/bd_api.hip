@@ -203,29 +203,39 @@ static int bd_check_batch_args(const int16_t *samples, uint64_t n_samples, uint6
 
 static int bd_candidates_impl(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                               uint64_t n_samples, uint64_t stride, uint32_t callback_len,
-                              float *values, uint8_t *flags, hipStream_t st)
+                              float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st)
 {
     if (plan.kind == BD_KIND_SPECTRUM)
-        return bd_launch_spectrum(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, st);
-    return bd_launch_lpf(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, st);
+        return bd_launch_spectrum(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, out_stride, st);
+    return bd_launch_lpf(plan, samples, n_streams, n_samples, stride, callback_len, values, flags, out_stride, st);
+}
+
+// out_stride == 0 means densely packed rows
+static int bd_resolve_out_stride(uint64_t *out_stride, uint64_t n_cb)
+{
+    if (*out_stride == 0) *out_stride = n_cb;
+    if (*out_stride < n_cb) { bd_set_error("out_stride (%llu) < callbacks per stream (%llu)", (unsigned long long)*out_stride, (unsigned long long)n_cb); return BD_ERR_INVALID_ARG; }
+    return BD_OK;
 }
 
 extern "C" int bd_batch_candidates(int kind, uint32_t sampling_rate, const bd_params *params,
                                    const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                    uint64_t stream_stride, uint32_t callback_len,
-                                   float *values, uint8_t *flags, void *hip_stream)
+                                   float *values, uint8_t *flags, uint64_t out_stride, void *hip_stream)
 {
     bd_plan plan;
     int s = bd_make_plan(kind, sampling_rate, params, &plan);
     if (s != BD_OK) return s;
     s = bd_check_batch_args(samples, n_samples, stream_stride, callback_len, flags);
     if (s != BD_OK) return s;
+    s = bd_resolve_out_stride(&out_stride, n_samples / callback_len);
+    if (s != BD_OK) return s;
     return bd_candidates_impl(plan, samples, n_streams, n_samples, stream_stride, callback_len,
-                              values, flags, (hipStream_t)hip_stream);
+                              values, flags, out_stride, (hipStream_t)hip_stream);
 }
 
 extern "C" int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t callback_len,
-                             const uint8_t *flags, uint64_t n_streams, uint64_t n_callbacks,
+                             const uint8_t *flags, uint64_t flags_stride, uint64_t n_streams, uint64_t n_callbacks,
                              uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                              uint32_t max_beats, void *hip_stream)
 {
@@ -233,14 +243,16 @@ extern "C" int bd_refractory(uint32_t sampling_rate, const bd_params *params, ui
     int s = bd_make_plan(BD_KIND_LPF, sampling_rate, params, &plan);
     if (s != BD_OK) return s;
     if (!flags || !beat_count || callback_len == 0) { bd_set_error("bd_refractory: bad arguments"); return BD_ERR_INVALID_ARG; }
-    return bd_launch_refractory(plan, callback_len, flags, n_streams, n_callbacks, beat_count,
+    s = bd_resolve_out_stride(&flags_stride, n_callbacks);
+    if (s != BD_OK) return s;
+    return bd_launch_refractory(plan, callback_len, flags, flags_stride, n_streams, n_callbacks, beat_count,
                                 beat_idx, beat_ms, max_beats, (hipStream_t)hip_stream);
 }
 
 extern "C" int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
                                 const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                 uint64_t stream_stride, uint32_t callback_len,
-                                float *values, uint8_t *flags,
+                                float *values, uint8_t *flags, uint64_t out_stride,
                                 uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                                 uint32_t max_beats, void *hip_stream)
 {
@@ -250,11 +262,13 @@ extern "C" int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_param
     s = bd_check_batch_args(samples, n_samples, stream_stride, callback_len, flags);
     if (s != BD_OK) return s;
     if (!beat_count) { bd_set_error("beat_count must not be NULL"); return BD_ERR_INVALID_ARG; }
+    s = bd_resolve_out_stride(&out_stride, n_samples / callback_len);
+    if (s != BD_OK) return s;
     hipStream_t st = (hipStream_t)hip_stream;
-    s = bd_candidates_impl(plan, samples, n_streams, n_samples, stream_stride, callback_len, values, flags, st);
+    s = bd_candidates_impl(plan, samples, n_streams, n_samples, stream_stride, callback_len, values, flags, out_stride, st);
     if (s != BD_OK) return s;
     const char *k = bd_last_kernel; // keep the dominant kernel's name
-    s = bd_launch_refractory(plan, callback_len, flags, n_streams, n_samples / callback_len,
+    s = bd_launch_refractory(plan, callback_len, flags, out_stride, n_streams, n_samples / callback_len,
                              beat_count, beat_idx, beat_ms, max_beats, st);
     bd_last_kernel = k;
     return s;
@@ -283,9 +297,11 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
                        uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
 {
     const uint64_t n_cb = n_samples / callback_len;
-    const uint64_t n_out = n_streams * n_cb;
-    // rows are repacked to a 16-byte aligned device stride so the fast kernels apply
+    // rows are repacked to a 16-byte aligned device stride so the fast kernels
+    // apply; output rows start on 128-byte boundaries (full-line stores)
     const uint64_t d_stride = (n_samples + 7) & ~7ull;
+    const uint64_t o_stride = (n_cb + 127) & ~127ull;
+    const uint64_t n_out = n_streams * o_stride;
     BD_HIP(hipStreamCreateWithFlags(&j.st, hipStreamNonBlocking));
     BD_HIP(hipMalloc((void **)&j.d_samples, (n_streams * d_stride + 8) * sizeof(int16_t)));
     if (n_out) {
@@ -301,11 +317,13 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
         BD_HIP(hipMemsetAsync(j.d_count, 0, n_streams * sizeof(uint32_t), j.st));
     } else {
         int s = bd_analyze_batch(kind, sampling_rate, params, j.d_samples, n_streams, n_samples, d_stride,
-                                 callback_len, j.d_values, j.d_flags, j.d_count, j.d_idx, j.d_ms,
+                                 callback_len, j.d_values, j.d_flags, o_stride, j.d_count, j.d_idx, j.d_ms,
                                  max_beats, j.st);
         if (s != BD_OK) return s;
-        if (values) BD_HIP(hipMemcpyAsync(values, j.d_values, n_out * sizeof(float), hipMemcpyDeviceToHost, j.st));
-        if (flags) BD_HIP(hipMemcpyAsync(flags, j.d_flags, n_out, hipMemcpyDeviceToHost, j.st));
+        if (values) BD_HIP(hipMemcpy2DAsync(values, n_cb * sizeof(float), j.d_values, o_stride * sizeof(float),
+                                            n_cb * sizeof(float), n_streams, hipMemcpyDeviceToHost, j.st));
+        if (flags) BD_HIP(hipMemcpy2DAsync(flags, n_cb, j.d_flags, o_stride, n_cb, n_streams,
+                                           hipMemcpyDeviceToHost, j.st));
     }
     BD_HIP(hipMemcpyAsync(beat_count, j.d_count, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
     if (j.d_idx) BD_HIP(hipMemcpyAsync(beat_idx, j.d_idx, n_streams * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));

@@ -42,12 +42,12 @@ int  bd_check_hip(hipError_t e, const char *what);
 // stage launchers (device pointers, enqueue only)
 int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                        uint64_t n_samples, uint64_t stride, uint32_t callback_len,
-                       float *values, uint8_t *flags, hipStream_t st);
+                       float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);
 int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                   uint64_t n_samples, uint64_t stride, uint32_t callback_len,
-                  float *values, uint8_t *flags, hipStream_t st);
+                  float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);
 int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8_t *flags,
-                         uint64_t n_streams, uint64_t n_cb, uint32_t *beat_count,
+                         uint64_t flags_stride, uint64_t n_streams, uint64_t n_cb, uint32_t *beat_count,
                          uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
                          hipStream_t st);
 

@@ -17,12 +17,15 @@
 // operations per sample.
 #include "bd_internal.h"
 
+#include <stdlib.h>
+
 struct bd_lpf_args {
     const int16_t *samples;
     float         *values;
     uint8_t       *flags;
     uint64_t       stride;      // samples between streams
     uint64_t       n_cb;        // callbacks per stream
+    uint64_t       out_stride;  // callbacks between the rows of values / flags
     uint64_t       n_tasks;     // n_streams * groups_per_stream
     uint32_t       groups_per_stream; // ceil(n_cb / 64)
     uint32_t       callback_len;
@@ -31,8 +34,10 @@ struct bd_lpf_args {
     float          ratio;
 };
 
-#define BD_LPF_CHUNK 64          // samples per window per chunk
-#define BD_LPF_ROW_U4 9          // LDS row = 8 x 16 B of data + 16 B of padding
+// CHUNK = samples of each window staged per step (64 or 128).  An LDS row holds
+// CHUNK samples plus 16 B of padding: 144 B or 272 B, i.e. a row stride of 36 or
+// 68 dwords, both = 4 (mod 32), which makes the per-lane ds_read_b128 of
+// "my row, piece p" conflict-free.
 
 __device__ __forceinline__ void bd_lpf_step(float x, float alpha, float &y, float &ymax, float &xmax)
 {
@@ -54,19 +59,24 @@ __device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, 
     float thr = truncf(a.ratio * wmax);
     thr = (thr != thr) ? 0.f : fminf(fmaxf(thr, -32768.f), 32767.f);
     const bool flag = gate && (ymax >= thr);                 // lpf.rs:75
-    const uint64_t o = s * a.n_cb + j;
+    const uint64_t o = s * a.out_stride + j;
     if (a.values) a.values[o] = gate ? ymax : 0.f;
     a.flags[o] = flag ? 1 : 0;
 }
 
 // ALIGNED: callback_len % 8 == 0, stride % 8 == 0, base 16-byte aligned.
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
+// WPB: wavefronts per workgroup (each has a private LDS tile).
+template <bool ALIGNED, int CHUNK, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
 {
-    __shared__ uint4 tile_all[4][64 * BD_LPF_ROW_U4];
+    constexpr int BD_LPF_CHUNK = CHUNK;
+    constexpr int PIECES = CHUNK / 8;          // 16-byte pieces per row and chunk
+    constexpr int BD_LPF_ROW_U4 = PIECES + 1;
+    constexpr int ROWS_PER_LOAD = 64 / PIECES; // rows covered by one load instruction
+    __shared__ uint4 tile_all[WPB][64 * BD_LPF_ROW_U4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint4 *tile = tile_all[wave];
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = (uint64_t)blockIdx.x * WPB + wave;
     if (task >= a.n_tasks) return; // wave-uniform
     const uint64_t s = task / a.groups_per_stream;
     const uint64_t j0 = (task - s * a.groups_per_stream) * 64;
@@ -80,14 +90,15 @@ __global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
     const float alpha = a.alpha;
 
     if (ALIGNED) {
-        // load instruction i covers windows 8 i + lane/8, 16-byte piece lane%8
-        const int lrow = lane >> 3, piece = lane & 7;
-        uint4 stage[8];
+        // load instruction i covers windows ROWS_PER_LOAD * i + lane / PIECES,
+        // 16-byte piece lane % PIECES: CHUNK * 2 contiguous bytes per window
+        const int lrow = lane / PIECES, piece = lane % PIECES;
+        uint4 stage[PIECES];
         auto load_chunk = [&](uint32_t ch) {
             const uint32_t first = ch * BD_LPF_CHUNK + piece * 8; // sample offset inside the window
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t row = 8 * i + lrow;
+            for (int i = 0; i < PIECES; i++) {
+                const uint32_t row = ROWS_PER_LOAD * i + lrow;
                 if (row < rows && first < L)
                     stage[i] = bd_load_stream16(gp + (uint64_t)row * L + first);
                 else
@@ -101,13 +112,13 @@ __global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                tile[(8 * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
+            for (int i = 0; i < PIECES; i++)
+                tile[(ROWS_PER_LOAD * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
             if (ch + 1 < n_chunks) load_chunk(ch + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t left = L - ch * BD_LPF_CHUNK;
-            const int pieces = left >= BD_LPF_CHUNK ? 8 : (int)(left / 8);
+            const int pieces = left >= (uint32_t)BD_LPF_CHUNK ? PIECES : (int)(left / 8);
             for (int p = 0; p < pieces; p++) {
                 const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t left = L - ch * BD_LPF_CHUNK;
-            const int cnt = left >= BD_LPF_CHUNK ? BD_LPF_CHUNK : (int)left;
+            const int cnt = left >= (uint32_t)BD_LPF_CHUNK ? BD_LPF_CHUNK : (int)left;
             for (int i = 0; i < cnt; i++)
                 bd_lpf_step((float)tile16[lane * row_i16 + i], alpha, y, ymax, xmax);
         }
@@ -140,15 +151,19 @@ __global__ __launch_bounds__(256) void bd_lpf_window_kernel(bd_lpf_args a)
     bd_lpf_finish(a, s, j0 + lane, valid, xmax, ymax);
 }
 
-__global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n)
+__global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n_cb, uint64_t out_stride, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { if (values) values[i] = 0.f; flags[i] = 0; }
+    if (i < n) {
+        const uint64_t o = (i / n_cb) * out_stride + i % n_cb;
+        if (values) values[o] = 0.f;
+        flags[o] = 0;
+    }
 }
 
 int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                   uint64_t n_samples, uint64_t stride, uint32_t callback_len,
-                  float *values, uint8_t *flags, hipStream_t st)
+                  float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st)
 {
     const uint64_t n_cb = n_samples / callback_len;
     if (n_cb == 0 || n_streams == 0) return BD_OK;
@@ -158,26 +173,35 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
         const uint64_t n = n_streams * n_cb;
         const uint64_t grid64 = (n + 255) / 256;
         if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(bd_fill_zero_kernel, dim3((unsigned)grid64), dim3(256), 0, st, values, flags, n);
+        hipLaunchKernelGGL(bd_fill_zero_kernel, dim3((unsigned)grid64), dim3(256), 0, st, values, flags, n_cb, out_stride, n);
         bd_set_last_kernel("bd_fill_zero_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_fill_zero_kernel");
     }
     bd_lpf_args a;
     a.samples = samples; a.values = values; a.flags = flags;
-    a.stride = stride; a.n_cb = n_cb;
+    a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;
     const uint64_t groups = (n_cb + 63) / 64;
     if (groups > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
     a.groups_per_stream = (uint32_t)groups;
     a.n_tasks = n_streams * groups;
     a.callback_len = callback_len; a.min_amp = plan.min_amp;
     a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
-    const uint64_t grid64 = (a.n_tasks + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0);
-    if (aligned)
-        hipLaunchKernelGGL((bd_lpf_window_kernel<true>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+    // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
+    // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
+    static const int variant_env = [] { const char *e = getenv("BD_LPF_VARIANT"); return e ? atoi(e) : 0; }();
+    const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
+    const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
+    const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;
+    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    if (!aligned)
+        hipLaunchKernelGGL((bd_lpf_window_kernel<false, 64, 4>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+    else if (variant == 1)
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 1>), dim3((unsigned)grid64), dim3(64), 0, st, a);
+    else if (variant == 2)
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 2>), dim3((unsigned)grid64), dim3(128), 0, st, a);
     else
-        hipLaunchKernelGGL((bd_lpf_window_kernel<false>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 64, 4>), dim3((unsigned)grid64), dim3(256), 0, st, a);
     bd_set_last_kernel("bd_lpf_window_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_lpf_window_kernel");
 }

@@ -29,6 +29,8 @@
 //   One wavefront per callback, ring gathered with 2-byte loads, twiddles from
 //   a 1024-entry table.
 #include "bd_internal.h"
+
+#include <stdlib.h>
 #include "bd_twiddles.inc"
 
 typedef short bd_short2 __attribute__((ext_vector_type(2)));
@@ -40,6 +42,7 @@ struct bd_spec_args {
     uint64_t       stride;          // samples between streams
     uint64_t       n_tasks;         // n_streams * runs_per_stream
     uint64_t       n_cb;            // callbacks per stream
+    uint64_t       out_stride;      // callbacks between the rows of values / flags
     uint32_t       n_hb;            // half-blocks per stream that belong to callbacks
     uint32_t       run_hbs;         // half-blocks per task (multiple of 4)
     uint32_t       runs_per_stream;
@@ -56,104 +59,87 @@ static __device__ const float bd_sin1024[1024] = {
 #include "bd_sin1024.inc"
 };
 
-__device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int64_t hb, int l, bool valid)
+// loads the four 16-byte pieces of one lane: half-block `hb`, bytes 256 c + 16 l
+__device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int64_t hb, int l)
 {
     const uint4 *p = reinterpret_cast<const uint4 *>(sp + hb * BD_HALF_BLOCK) + l;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        if (valid) d[c] = bd_load_stream16(p + 16 * c);
-        else d[c] = make_uint4(0, 0, 0, 0);
-    }
+    for (int c = 0; c < 4; c++) d[c] = bd_load_stream16(p + 16 * c);
 }
 
-// MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
-// NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
+#define BD_SPEC_MAX_RUN 512 // half-blocks per task, upper bound (LDS flag staging)
+
+// per-wavefront state that lives across iterations
+struct bd_spec_carry {
+    // sums of the last half-block of the previous iteration (wave-uniform)
+    float re1, im1, re2, im2, amax;
+    int   dc, ny;
+    float   *lds_v;   // [BD_SPEC_MAX_RUN] values of the whole run
+    uint8_t *lds_f;   // [BD_SPEC_MAX_RUN] decisions of the whole run
+};
+
+// One iteration: four half-blocks (one per row of 16 lanes) held in `d`.
 template <int MODE, int NK, bool NYQ>
-__global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
+__device__ __forceinline__ void bd_spec_iter(const bd_spec_args &a, const uint4 (&d)[4], int it, int64_t hb,
+                                             int64_t n_hb, uint64_t s, int g, int l,
+                                             float lc1, float ls1, float lc2, float ls2, bd_spec_carry &k)
 {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, l = lane & 15;
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (task >= a.n_tasks) return; // wave-uniform
-    const uint64_t s = task / a.runs_per_stream;
-    const uint32_t r = (uint32_t)(task - s * a.runs_per_stream);
-    const int64_t hb0 = (int64_t)r * a.run_hbs;
-    const int16_t *sp = a.samples + s * a.stride;
-    const int64_t n_hb = a.n_hb;
-    const int n_it = (int)(a.run_hbs / 4);
-    // hop 512: the first callback of a run needs the half-block before the run
-    const int it_begin = (MODE == 0 && hb0 > 0) ? -1 : 0;
-    const int64_t hb_lo = (MODE == 0) ? hb0 - 1 : hb0;
-
-    const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
-    const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
-
-    // carried sums of the last half-block of the previous iteration
-    float c_re1 = 0.f, c_im1 = 0.f, c_re2 = 0.f, c_im2 = 0.f, c_amax = 0.f;
-    int c_dc = 0, c_ny = 0;
-
-    uint4 cur[4], nxt[4];
-    {
-        int64_t hb = hb0 + 4 * (int64_t)it_begin + g;
-        bd_load_hb(cur, sp, hb, l, hb >= hb_lo && hb >= 0 && hb < n_hb);
-    }
-    for (int it = it_begin; it < n_it; it++) {
-        const int64_t hb = hb0 + 4 * (int64_t)it + g;
-        if (hb0 + 4 * (int64_t)it >= n_hb) break; // wave-uniform
-        {
-            int64_t hbn = hb + 4;
-            bool vn = (it + 1 < n_it) && hbn >= hb_lo && hbn < n_hb;
-            bd_load_hb(nxt, sp, hbn, l, vn);
-        }
-        float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
-        int dc = 0, ny = 0;
+    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
+    int dc = 0, ny = 0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const unsigned w[4] = {cur[c].x, cur[c].y, cur[c].z, cur[c].w};
+    for (int c = 0; c < 4; c++) {
+        const unsigned w[4] = {d[c].x, d[c].y, d[c].z, d[c].w};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int d = (int)w[q];
-                const float x0 = (float)(short)(d & 0xffff);
-                const float x1 = (float)(short)(d >> 16);
-                const int i0 = c * 8 + 2 * q, i1 = i0 + 1;
-                dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, d), bd_short2{1, 1}, dc, false);
-                if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, d), bd_short2{1, -1}, ny, false);
-                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
-                if (NK >= 1) {
-                    a1 = __builtin_fmaf(x0, BD_TW_C[0][i0], a1); b1 = __builtin_fmaf(x0, BD_TW_S[0][i0], b1);
-                    a1 = __builtin_fmaf(x1, BD_TW_C[0][i1], a1); b1 = __builtin_fmaf(x1, BD_TW_S[0][i1], b1);
-                }
-                if (NK >= 2) {
-                    a2 = __builtin_fmaf(x0, BD_TW_C[1][i0], a2); b2 = __builtin_fmaf(x0, BD_TW_S[1][i0], b2);
-                    a2 = __builtin_fmaf(x1, BD_TW_C[1][i1], a2); b2 = __builtin_fmaf(x1, BD_TW_S[1][i1], b2);
-                }
+        for (int q = 0; q < 4; q++) {
+            const int v = (int)w[q];
+            const float x0 = (float)(short)(v & 0xffff);
+            const float x1 = (float)(short)(v >> 16);
+            const int i0 = c * 8 + 2 * q, i1 = i0 + 1;
+            dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, dc, false);
+            if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, -1}, ny, false);
+            amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+            if (NK >= 1) {
+                a1 = __builtin_fmaf(x0, BD_TW_C[0][i0], a1); b1 = __builtin_fmaf(x0, BD_TW_S[0][i0], b1);
+                a1 = __builtin_fmaf(x1, BD_TW_C[0][i1], a1); b1 = __builtin_fmaf(x1, BD_TW_S[0][i1], b1);
+            }
+            if (NK >= 2) {
+                a2 = __builtin_fmaf(x0, BD_TW_C[1][i0], a2); b2 = __builtin_fmaf(x0, BD_TW_S[1][i0], b2);
+                a2 = __builtin_fmaf(x1, BD_TW_C[1][i1], a2); b2 = __builtin_fmaf(x1, BD_TW_S[1][i1], b2);
             }
         }
-        // (a - i b) * (cos - i sin): apply the per-lane offset 8 l, then reduce the row
-        float re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f;
-        if (NK >= 1) {
-            re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
-            im1 = bd_row_sum(a1 * ls1 + b1 * lc1);
-        }
-        if (NK >= 2) {
-            re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
-            im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
-        }
-        dc = bd_row_sum(dc);
-        if (NYQ) ny = bd_row_sum(ny);
-        amax = bd_row_max(amax);
+    }
+    // (a - i b) * (cos - i sin): apply the per-lane offset 8 l, then reduce the row
+    float re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f;
+    if (NK >= 1) {
+        re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
+        im1 = bd_row_sum(a1 * ls1 + b1 * lc1);
+    }
+    if (NK >= 2) {
+        re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
+        im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
+    }
+    dc = bd_row_sum(dc);
+    if (NYQ) ny = bd_row_sum(ny);
+    amax = bd_row_max(amax);
 
-        // sums of the half-block just before this row's
-        const float p_re1 = bd_prev_row(re1, c_re1), p_im1 = bd_prev_row(im1, c_im1);
-        const float p_re2 = bd_prev_row(re2, c_re2), p_im2 = bd_prev_row(im2, c_im2);
-        const float p_amax = bd_prev_row(amax, c_amax);
-        const int p_dc = bd_prev_row(dc, c_dc);
-        const int p_ny = NYQ ? bd_prev_row(ny, c_ny) : 0;
-        c_re1 = bd_lane63(re1); c_im1 = bd_lane63(im1);
-        c_re2 = bd_lane63(re2); c_im2 = bd_lane63(im2);
-        c_amax = bd_lane63(amax); c_dc = bd_lane63(dc);
-        if (NYQ) c_ny = bd_lane63(ny);
+    // sums of the half-block just before this row's
+    const float p_re1 = bd_prev_row(re1, k.re1), p_im1 = bd_prev_row(im1, k.im1);
+    const float p_re2 = bd_prev_row(re2, k.re2), p_im2 = bd_prev_row(im2, k.im2);
+    const float p_amax = bd_prev_row(amax, k.amax);
+    const int p_dc = bd_prev_row(dc, k.dc);
+    const int p_ny = NYQ ? bd_prev_row(ny, k.ny) : 0;
+    if (MODE == 0) { // only the hop-512 ring reaches back into the previous iteration
+        k.re1 = bd_lane63(re1); k.im1 = bd_lane63(im1);
+        k.re2 = bd_lane63(re2); k.im2 = bd_lane63(im2);
+        k.dc = bd_lane63(dc);
+        if (NYQ) k.ny = bd_lane63(ny);
+    }
 
+    // Lane 0 of each row finishes the row's callback and parks the result in
+    // LDS; the results of the whole run are stored at its end by consecutive
+    // lanes (contiguous, full cache lines when the output rows are 128-byte
+    // aligned) instead of 4-byte and 1-byte stores from four lanes per iteration.
+    if (l == 0 && it >= 0 && (MODE == 0 || (g & 1))) {
         // X_k = P_k(prev) + (-1)^k P_k(cur)
         const float x_dc = (float)(p_dc + dc);
         float m0 = fabsf(x_dc);
@@ -164,30 +150,92 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         float best = a.include_dc ? m0 : 0.f;
         if (NK >= 1) {
             const float xr = p_re1 - re1, xi = p_im1 - im1;
-            const float m1 = sqrtf(xr * xr + xi * xi);
-            best = fmaxf(best, m1);
+            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
         }
         if (NK >= 2) {
             const float xr = p_re2 + re2, xi = p_im2 + im2;
-            const float m2 = sqrtf(xr * xr + xi * xi);
-            best = fmaxf(best, m2);
+            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
         }
         const float value = (a.divisor == 0.f) ? best : best / a.divisor;
         const float wmax = fminf(MODE == 0 ? amax : fmaxf(amax, p_amax), 32767.f);
         const bool gate = wmax >= (float)a.min_amp;
-        const bool flag = gate && (value > a.threshold);
+        const int r = MODE == 0 ? g : (g >> 1);
+        constexpr int RPI = MODE == 0 ? 4 : 2;
+        k.lds_v[RPI * it + r] = value;
+        k.lds_f[RPI * it + r] = (gate && (value > a.threshold)) ? 1 : 0;
+    }
+}
 
-        bool writer = (l == 0) && it >= 0 && hb < n_hb;
-        uint64_t cb;
-        if (MODE == 0) cb = (uint64_t)hb;
-        else { writer = writer && (g & 1); cb = (uint64_t)(hb >> 1); }
-        if (writer) {
-            const uint64_t o = s * a.n_cb + cb;
-            if (a.values) a.values[o] = value;
-            a.flags[o] = flag ? 1 : 0;
+// MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
+// NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
+template <int MODE, int NK, bool NYQ>
+__global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
+{
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, l = lane & 15;
+    // everything that selects the task is the same in all lanes: keep it scalar
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    if (task >= a.n_tasks) return;
+    const uint64_t s = task / a.runs_per_stream;
+    const uint32_t r = (uint32_t)(task - s * a.runs_per_stream);
+    const int64_t hb0 = (int64_t)r * a.run_hbs;
+    const int16_t *sp = a.samples + s * a.stride;
+    const int64_t n_hb = a.n_hb;
+    // iterations of this run that contain at least one half-block of the stream
+    const int64_t left = n_hb - hb0;
+    const int n_it = (int)((left < (int64_t)a.run_hbs ? left + 3 : (int64_t)a.run_hbs) / 4);
+    // hop 512: the first callback of a run needs the half-block before the run
+    const int it_begin = (MODE == 0 && hb0 > 0) ? -1 : 0;
+    const int64_t hb_lo = (MODE == 0) ? hb0 - 1 : hb0;
+
+    const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
+    const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
+
+    bd_spec_carry k;
+    k.re1 = k.im1 = k.re2 = k.im2 = k.amax = 0.f;
+    k.dc = k.ny = 0;
+    __shared__ float lds_values[4][BD_SPEC_MAX_RUN];
+    __shared__ uint8_t lds_flags[4][BD_SPEC_MAX_RUN];
+    k.lds_v = lds_values[wave];
+    k.lds_f = lds_flags[wave];
+
+    // Two register buffers, each filled one iteration ahead of its use.  Loads
+    // are unconditional so that the compiler can count them (s_waitcnt vmcnt(4)
+    // instead of vmcnt(0)): a half-block outside [hb_lo, n_hb) is replaced by
+    // the nearest one inside (a line some lane of this wavefront reads anyway)
+    // and an iteration past the end by the last one.  Rows that loaded such a
+    // stand-in produce values that are never stored, and no stored value
+    // depends on them: a row's "previous half-block" is always a real one.
+    uint4 A[4], B[4];
+    auto load = [&](uint4 (&d)[4], int it) {
+        const int itc = it < n_it - 1 ? it : n_it - 1;
+        int64_t hb = hb0 + 4 * (int64_t)itc + g;
+        hb = hb < hb_lo ? hb_lo : hb;
+        hb = hb < n_hb - 1 ? hb : n_hb - 1;
+        bd_load_hb(d, sp, hb, l);
+    };
+    auto run = [&](const uint4 (&d)[4], int it) {
+        bd_spec_iter<MODE, NK, NYQ>(a, d, it, hb0 + 4 * (int64_t)it + g, n_hb, s, g, l, lc1, ls1, lc2, ls2, k);
+    };
+    load(A, it_begin);
+    for (int it = it_begin; it < n_it; it += 2) {
+        load(B, it + 1);
+        run(A, it);
+        load(A, it + 2);
+        if (it + 1 < n_it) run(B, it + 1);
+    }
+    // results of the run: consecutive lanes store consecutive callbacks
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t cb0 = (uint64_t)(hb0 >> MODE);
+    const int n_res = n_it * (MODE == 0 ? 4 : 2);
+    const uint64_t o0 = s * a.out_stride + cb0;
+    for (int i = lane; i < n_res; i += 64) {
+        if (cb0 + i < a.n_cb) {
+            if (a.values) a.values[o0 + i] = k.lds_v[i];
+            a.flags[o0 + i] = k.lds_f[i];
         }
-#pragma unroll
-        for (int c = 0; c < 4; c++) cur[c] = nxt[c];
     }
 }
 
@@ -199,6 +247,7 @@ struct bd_spec_generic_args {
     uint64_t       stride;
     uint64_t       n_cb;
     uint64_t       n_total;  // n_streams * n_cb
+    uint64_t       out_stride;
     uint32_t       callback_len;
     uint32_t       min_amp;
     int            first_bin, last_bin;
@@ -252,8 +301,9 @@ __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generi
     const float value = (a.divisor == 0.f) ? best : best / a.divisor;
     const bool flag = (amax >= (float)a.min_amp) && (value > a.threshold);
     if (lane == 0) {
-        if (a.values) a.values[t] = value;
-        a.flags[t] = flag ? 1 : 0;
+        const uint64_t o = s * a.out_stride + j;
+        if (a.values) a.values[o] = value;
+        a.flags[o] = flag ? 1 : 0;
     }
 }
 
@@ -267,7 +317,7 @@ static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, hipStrea
 
 int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                        uint64_t n_samples, uint64_t stride, uint32_t callback_len,
-                       float *values, uint8_t *flags, hipStream_t st)
+                       float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st)
 {
     const uint64_t n_cb = n_samples / callback_len;
     if (n_cb == 0 || n_streams == 0) return BD_OK;
@@ -277,7 +327,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     if (aligned && fast_len && fast_bins) {
         bd_spec_args a;
         a.samples = samples; a.values = values; a.flags = flags;
-        a.stride = stride; a.n_cb = n_cb;
+        a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;
         const uint64_t n_hb = n_cb * (callback_len / BD_HALF_BLOCK);
         if (n_hb > 0xffffffffull) { bd_set_error("stream too long for the fast Spectrum kernel"); return BD_ERR_UNSUPPORTED; }
         a.n_hb = (uint32_t)n_hb;
@@ -285,6 +335,8 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         // start; short streams still need enough wavefronts to fill 256 CUs.
         uint32_t run = 128;
         while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
+        static const int run_override = [] { const char *e = getenv("BD_SPEC_RUN"); return e ? atoi(e) : 0; }();
+        if (run_override >= 8 && run_override % 8 == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
         a.run_hbs = run;
         a.runs_per_stream = (uint32_t)((n_hb + run - 1) / run);
         a.n_tasks = n_streams * a.runs_per_stream;
@@ -309,7 +361,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     }
     bd_spec_generic_args a;
     a.samples = samples; a.values = values; a.flags = flags;
-    a.stride = stride; a.n_cb = n_cb; a.n_total = n_streams * n_cb;
+    a.stride = stride; a.n_cb = n_cb; a.n_total = n_streams * n_cb; a.out_stride = out_stride;
     a.callback_len = callback_len; a.min_amp = plan.min_amp;
     a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
     a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;

@@ -88,8 +88,10 @@ def main() -> None:
     bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=seed, sampling_rate=sr)
     n_cb = n // L
     max_beats = max(1, bd.batch_max_beats(kind, sr, n, L))
-    values = torch.empty((streams, n_cb), dtype=torch.float32, device=dev)
-    flags = torch.empty((streams, n_cb), dtype=torch.uint8, device=dev)
+    # output rows start on 128-byte boundaries so that every store is a full line
+    out_stride = (n_cb + 127) & ~127
+    values = torch.empty((streams, out_stride), dtype=torch.float32, device=dev)
+    flags = torch.empty((streams, out_stride), dtype=torch.uint8, device=dev)
     count = torch.zeros((streams,), dtype=torch.int32, device=dev)
     idx = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
     ms = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
@@ -100,12 +102,12 @@ def main() -> None:
 
     def stage1():
         rc = L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
-                                    values.data_ptr(), flags.data_ptr(), st)
+                                    values.data_ptr(), flags.data_ptr(), out_stride, st)
         if rc != 0:
             raise RuntimeError(L_.bd_last_error().decode())
 
     def stage2():
-        rc = L_.bd_refractory(sr, None, L, flags.data_ptr(), streams, n_cb, count.data_ptr(), idx.data_ptr(),
+        rc = L_.bd_refractory(sr, None, L, flags.data_ptr(), out_stride, streams, n_cb, count.data_ptr(), idx.data_ptr(),
                               ms.data_ptr(), max_beats, st)
         if rc != 0:
             raise RuntimeError(L_.bd_last_error().decode())

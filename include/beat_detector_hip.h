@@ -120,8 +120,10 @@ uint32_t bd_batch_max_beats(uint32_t kind, uint32_t sampling_rate, const bd_para
 
 /* All pointers are device pointers on the current device.
  *   samples   [n_streams][stream_stride] i16, the first n_samples of each row used
- *   values    [n_streams][n_callbacks] f32 or NULL   analysed value per callback
- *   flags     [n_streams][n_callbacks] u8            decision before the refractory rule
+ *   values    [n_streams][out_stride] f32 or NULL    analysed value per callback
+ *   flags     [n_streams][out_stride] u8             decision before the refractory rule
+ *             (the first n_callbacks entries of each row are written; out_stride = 0
+ *             means n_callbacks; a multiple of 128 makes every store a full line)
  *   beat_count[n_streams] u32                        beats found (may exceed max_beats)
  *   beat_idx  [n_streams][max_beats] u32 or NULL     callback index of each beat
  *   beat_ms   [n_streams][max_beats] u32 or NULL     BeatInfo::relative_ms of each beat
@@ -130,7 +132,7 @@ uint32_t bd_batch_max_beats(uint32_t kind, uint32_t sampling_rate, const bd_para
 int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
                      const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                      uint64_t stream_stride, uint32_t callback_len,
-                     float *values, uint8_t *flags,
+                     float *values, uint8_t *flags, uint64_t out_stride,
                      uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                      uint32_t max_beats, void *hip_stream);
 
@@ -140,7 +142,7 @@ int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
 int bd_batch_candidates(int kind, uint32_t sampling_rate, const bd_params *params,
                         const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                         uint64_t stream_stride, uint32_t callback_len,
-                        float *values, uint8_t *flags, void *hip_stream);
+                        float *values, uint8_t *flags, uint64_t out_stride, void *hip_stream);
 
 /* Same analysis with every pointer in host memory; copies to `device`
  * (< 0: current), runs, copies back and synchronises.  values/flags/beat_idx/
@@ -163,9 +165,10 @@ int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd_params *pa
 
 /* The refractory rule alone (Strategy::last_beat_beyond_threshold,
  * src/lib.rs:115-127, with the clock of src/strategies/mod.rs:76-84) applied
- * to per-callback decisions already on the device. */
+ * to per-callback decisions already on the device (rows of flags_stride
+ * bytes, 0 = n_callbacks). */
 int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t callback_len,
-                  const uint8_t *flags, uint64_t n_streams, uint64_t n_callbacks,
+                  const uint8_t *flags, uint64_t flags_stride, uint64_t n_streams, uint64_t n_callbacks,
                   uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                   uint32_t max_beats, void *hip_stream);
 
