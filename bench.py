@@ -82,7 +82,9 @@ def main() -> None:
     n = sr * seconds
     stride = (n + 7) & ~7
     seed = 0x5EED
-    first_stream = rank * streams  # every rank analyses different streams
+    # weak scaling: `streams` per GPU, rank r owns the r-th contiguous shard of world * streams
+    from beat_detector_amd import sharding
+    first_stream = sharding.shard_range(world * streams, rank, world)[0]
 
     samples = torch.empty((streams, stride), dtype=torch.int16, device=dev)
     bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=seed, sampling_rate=sr)
