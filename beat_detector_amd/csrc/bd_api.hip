@@ -297,9 +297,9 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
                        uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
 {
     const uint64_t n_cb = n_samples / callback_len;
-    // rows are repacked to a 16-byte aligned device stride so the fast kernels
-    // apply; output rows start on 128-byte boundaries (full-line stores)
-    const uint64_t d_stride = (n_samples + 7) & ~7ull;
+    // input and output rows are repacked so that each starts on a 128-byte
+    // boundary: the fast kernels apply and every load / store covers whole lines
+    const uint64_t d_stride = (n_samples + 63) & ~63ull;
     const uint64_t o_stride = (n_cb + 127) & ~127ull;
     const uint64_t n_out = n_streams * o_stride;
     BD_HIP(hipStreamCreateWithFlags(&j.st, hipStreamNonBlocking));

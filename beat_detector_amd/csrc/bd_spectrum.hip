@@ -203,14 +203,13 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // Two register buffers, each filled one iteration ahead of its use.  Loads
     // are unconditional so that the compiler can count them (s_waitcnt vmcnt(4)
     // instead of vmcnt(0)): a half-block outside [hb_lo, n_hb) is replaced by
-    // the nearest one inside (a line some lane of this wavefront reads anyway)
-    // and an iteration past the end by the last one.  Rows that loaded such a
+    // the nearest one inside (a line some lane of this wavefront reads anyway).
+    // Rows that loaded such a
     // stand-in produce values that are never stored, and no stored value
     // depends on them: a row's "previous half-block" is always a real one.
     uint4 A[4], B[4];
     auto load = [&](uint4 (&d)[4], int it) {
-        const int itc = it < n_it - 1 ? it : n_it - 1;
-        int64_t hb = hb0 + 4 * (int64_t)itc + g;
+        int64_t hb = hb0 + 4 * (int64_t)it + g;
         hb = hb < hb_lo ? hb_lo : hb;
         hb = hb < n_hb - 1 ? hb : n_hb - 1;
         bd_load_hb(d, sp, hb, l);
@@ -218,12 +217,22 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     auto run = [&](const uint4 (&d)[4], int it) {
         bd_spec_iter<MODE, NK, NYQ>(a, d, it, hb0 + 4 * (int64_t)it + g, n_hb, s, g, l, lc1, ls1, lc2, ls2, k);
     };
-    load(A, it_begin);
-    for (int it = it_begin; it < n_it; it += 2) {
+    // Steady state: every load is issued one iteration ahead of its use.  The
+    // last one or two iterations are peeled so that nothing is loaded twice.
+    int it = it_begin;
+    load(A, it);
+    for (; it + 2 < n_it; it += 2) {
         load(B, it + 1);
         run(A, it);
         load(A, it + 2);
-        if (it + 1 < n_it) run(B, it + 1);
+        run(B, it + 1);
+    }
+    if (it + 1 < n_it) {
+        load(B, it + 1);
+        run(A, it);
+        run(B, it + 1);
+    } else {
+        run(A, it);
     }
     // results of the run: consecutive lanes store consecutive callbacks
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -80,7 +80,7 @@ def main() -> None:
     kind = bd.StrategyKind[kind_name]
     sr = 44100
     n = sr * seconds
-    stride = (n + 7) & ~7
+    stride = (n + 63) & ~63  # rows start on 128-byte boundaries
     seed = 0x5EED
     # weak scaling: `streams` per GPU, rank r owns the r-th contiguous shard of world * streams
     from beat_detector_amd import sharding

@@ -6,8 +6,9 @@ import beat_detector_amd as bd
 
 streams = int(os.environ.get("EXP_STREAMS", "8192"))
 sr, n = 44100, 44100 * 60
-buf = torch.empty((streams, n), dtype=torch.int16, device="cuda")
-bd.synth_fill(buf, seed=1)
+stride = (n + 63) & ~63 if os.environ.get("EXP_ALIGN", "1") == "1" else n
+buf = torch.empty((streams, stride), dtype=torch.int16, device="cuda")
+bd.synth_fill(buf, n_samples=n, seed=1)
 torch.cuda.synchronize()
 
 def timeit(kind, L, want_values=True, reps=5):
@@ -16,12 +17,12 @@ def timeit(kind, L, want_values=True, reps=5):
     vals = _out_rows(streams, n_cb, torch.float32, "cuda") if want_values else None
     flags = _out_rows(streams, n_cb, torch.uint8, "cuda")
     for _ in range(2):
-        bd.batch_candidates(kind, sr, buf, L, values=vals, flags=flags, want_values=want_values)
+        bd.batch_candidates(kind, sr, buf, L, n_samples=n, values=vals, flags=flags, want_values=want_values)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        bd.batch_candidates(kind, sr, buf, L, values=vals, flags=flags, want_values=want_values)
+        bd.batch_candidates(kind, sr, buf, L, n_samples=n, values=vals, flags=flags, want_values=want_values)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
