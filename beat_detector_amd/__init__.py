@@ -10,6 +10,10 @@ fails loudly when the library or a GPU is missing.
 from .api import (  # noqa: F401
     BeatInfo,
     BeatDetectorError,
+    FMT_F32,
+    FMT_I16,
+    FMT_U16,
+    Live,
     Params,
     Strategy,
     StrategyKind,
@@ -25,6 +29,7 @@ from .api import (  # noqa: F401
     lib,
     lib_path,
     refractory,
+    start_listening,
     synth_fill,
     synth_fill_host,
     u16_data_to_i16,

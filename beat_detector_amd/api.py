@@ -66,6 +66,26 @@ class Params(C.Structure):
         return p
 
 
+LIVE_ON_BEAT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32)
+ON_BEAT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32)
+READ_FN = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)
+
+FMT_I16, FMT_U16, FMT_F32 = 0, 1, 2
+_FMT_DTYPE = {FMT_I16: np.int16, FMT_U16: np.uint16, FMT_F32: np.float32}
+
+
+class InputSource(C.Structure):
+    """bd_input_source: the stand-in for a cpal input device."""
+
+    _fields_ = [
+        ("sampling_rate", C.c_uint32),
+        ("sample_format", C.c_int),
+        ("max_callback_len", C.c_uint32),
+        ("read", READ_FN),
+        ("user", C.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -111,6 +131,13 @@ def lib() -> C.CDLL:
         "bd_synth_fill": (i32, [vp, u64, u64, u64, u64, u64, u32, vp]),
         "bd_synth_fill_host": (i32, [vp, u64, u64, u64, u64, u64, u32]),
         "bd_last_kernel_name": (C.c_char_p, []),
+        "bd_live_create": (i32, [i32, u32, pp, u32, u32, u32, i32, C.POINTER(vp)]),
+        "bd_live_set_on_beat": (i32, [vp, LIVE_ON_BEAT_FN, vp]),
+        "bd_live_submit": (i32, [vp, vp, u32, i32, C.POINTER(u64)]),
+        "bd_live_poll": (i32, [vp, u64, i32, vp, vp, vp]),
+        "bd_live_destroy": (None, [vp]),
+        "bd_start_listening": (i32, [ON_BEAT_FN, vp, C.POINTER(InputSource), i32, C.POINTER(C.c_int), C.POINTER(vp)]),
+        "bd_listener_join": (i32, [vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -126,7 +153,8 @@ EXPORTED_SYMBOLS = (
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_batch_candidates bd_analyze_batch_host "
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
-    "bd_synth_fill_host bd_last_kernel_name"
+    "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
+    "bd_live_destroy bd_start_listening bd_listener_join"
 ).split()
 
 
@@ -444,3 +472,93 @@ def synth_fill_host(n_streams: int, n_samples: int, first_stream: int = 0, seed:
     _check(lib().bd_synth_fill_host(out.ctypes.data_as(C.c_void_p), n_streams, n_samples, n_samples, first_stream,
                                     seed, sampling_rate))
     return out
+
+
+# --------------------------------------------------------------------------
+# Live path
+# --------------------------------------------------------------------------
+class Live:
+    """bd_live: n_streams detectors advanced together, one callback per stream and
+    tick, through a ring of pinned staging buffers and a HIP graph per tick."""
+
+    def __init__(self, kind: StrategyKind, sampling_rate: int, n_streams: int, max_callback_len: int = 4096,
+                 depth: int = 4, params: Optional[Params] = None, device: int = -1, on_beat=None):
+        self._h = C.c_void_p()
+        self.n_streams = n_streams
+        _check(lib().bd_live_create(kind.value, sampling_rate, _pp(params), n_streams, max_callback_len, depth, device,
+                                    C.byref(self._h)))
+        self._cb = None
+        if on_beat is not None:
+            self._cb = LIVE_ON_BEAT_FN(lambda user, stream, ms: on_beat(stream, BeatInfo(ms)))
+            _check(lib().bd_live_set_on_beat(self._h, self._cb, None))
+
+    def submit(self, samples, fmt: int = FMT_I16) -> int:
+        a = np.ascontiguousarray(samples, dtype=_FMT_DTYPE[fmt])
+        if a.ndim != 2 or a.shape[0] != self.n_streams:
+            raise BeatDetectorError(BD_ERR_INVALID_ARG, "samples must be [n_streams, n]")
+        tick = C.c_uint64(0)
+        _check(lib().bd_live_submit(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], fmt, C.byref(tick)))
+        return tick.value
+
+    def poll(self, tick: int, wait: bool = True):
+        """None if the tick has not finished; else (beats u8[n], relative_ms u32[n], values f32[n])."""
+        beats = np.zeros(self.n_streams, dtype=np.uint8)
+        ms = np.zeros(self.n_streams, dtype=np.uint32)
+        vals = np.zeros(self.n_streams, dtype=np.float32)
+        vp = lambda x: x.ctypes.data_as(C.c_void_p)
+        r = _check(lib().bd_live_poll(self._h, tick, 1 if wait else 0, vp(beats), vp(ms), vp(vals)))
+        return (beats, ms, vals) if r == 1 else None
+
+    def close(self) -> None:
+        if self._h:
+            lib().bd_live_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Listener:
+    """JoinHandle of start_listening."""
+
+    def __init__(self, handle, keep):
+        self._h, self._keep = handle, keep
+
+    def join(self) -> None:
+        if self._h:
+            h, self._h = self._h, None
+            _check(lib().bd_listener_join(h))
+
+
+def start_listening(on_beat_cb, input_dev, strategy: StrategyKind, keep_recording) -> Listener:
+    """record::start_listening(on_beat_cb, input_dev, strategy, keep_recording),
+    src/record.rs:39-44.  `input_dev` stands in for the cpal device: an object
+    with `sampling_rate`, `sample_format` (FMT_*), optional `max_callback_len`
+    and `read(capacity) -> numpy array` (empty array = end of stream), or None.
+    `keep_recording` is a ctypes.c_int used as the AtomicBool.  Raises
+    BeatDetectorError where the reference returns Err(String)."""
+    keep_refs = []
+    src_ptr = None
+    if input_dev is not None:
+        fmt = int(input_dev.sample_format)
+        dtype = _FMT_DTYPE[fmt]
+
+        def _read(user, buf, capacity):
+            data = np.ascontiguousarray(input_dev.read(int(capacity)), dtype=dtype)
+            n = min(int(data.size), int(capacity))
+            if n:
+                C.memmove(buf, data.ctypes.data, n * data.itemsize)
+            return n
+
+        read_c = READ_FN(_read)
+        src = InputSource(int(input_dev.sampling_rate), fmt, int(getattr(input_dev, "max_callback_len", 0)), read_c, None)
+        keep_refs += [read_c, src, input_dev]
+        src_ptr = C.byref(src)
+    cb_c = ON_BEAT_FN(lambda user, ms: on_beat_cb(BeatInfo(ms)))
+    keep_refs += [cb_c, keep_recording]
+    h = C.c_void_p()
+    _check(lib().bd_start_listening(cb_c, None, src_ptr, strategy.value, C.byref(keep_recording), C.byref(h)))
+    return Listener(h, keep_refs)

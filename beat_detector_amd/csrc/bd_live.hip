@@ -11,6 +11,8 @@
 #include "bd_internal.h"
 
 #include <new>
+#include <string>
+#include <vector>
 #include <string.h>
 
 static __device__ const float bd_cos1024[1024] = {
@@ -308,4 +310,367 @@ extern "C" int bd_detector_last(const bd_detector *d, float *value, int *candida
     if (value) *value = d->last.value;
     if (candidate) *candidate = (int)d->last.candidate;
     return BD_OK;
+}
+
+// =============================================================================
+// Multi-stream live engine: the successor of record::start_listening's callback
+// loop (src/record.rs:87-146) for M concurrent streams.  Every tick carries one
+// callback of n samples for each stream.  Ticks go through a ring of K slots
+// (pinned host staging, device staging, device and pinned result buffers); a
+// tick is one replay of a captured HIP graph: host-to-device copy, optional
+// ingest conversion (record.rs:151-166), the live kernel, device-to-host copy
+// of the results.  All ticks run on one stream, in order, so detector state
+// advances exactly as in the reference.  If an on_beat callback is installed a
+// dispatcher thread calls it in tick order, stream order, off the submitting
+// thread (the reference runs on_beat_cb on the audio thread: record.rs:96).
+// =============================================================================
+#include <atomic>
+#include <condition_variable>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <tuple>
+
+__global__ void bd_live_convert_kernel(const void *in, int16_t *out, uint64_t n, int format)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (format == BD_FMT_U16) {
+        const int32_t x = (int32_t)((const uint16_t *)in)[i] - (int32_t)(INT16_MAX / 2); // record.rs:154-155
+        out[i] = (int16_t)(uint16_t)(uint32_t)x;                                       // :156
+    } else {
+        float t = truncf(((const float *)in)[i] * 32767.0f);                           // record.rs:163-164
+        t = (t != t) ? 0.f : fminf(fmaxf(t, -32768.f), 32767.f);
+        out[i] = (int16_t)(int)t;
+    }
+}
+
+struct bd_live_slot {
+    void           *h_in = nullptr;     // pinned, M * max_len * 4 bytes
+    void           *d_raw = nullptr;    // device copy of h_in
+    int16_t        *d_i16 = nullptr;    // converted samples (unused for i16 input)
+    bd_live_result *d_res = nullptr;    // [M]
+    bd_live_result *h_res = nullptr;    // pinned [M]
+    hipEvent_t      done = nullptr;
+    uint64_t        tick = 0;           // tick currently in the slot (valid if busy)
+    bool            busy = false;
+    std::map<std::tuple<uint32_t, int>, hipGraphExec_t> graphs; // (n, format) -> graph
+};
+
+struct bd_live {
+    bd_plan        plan;
+    int            device = 0;
+    uint32_t       n_streams = 0, max_len = 0, depth = 0;
+    hipStream_t    stream = nullptr;
+    int16_t       *d_ring = nullptr;
+    bd_live_state *d_state = nullptr;
+    std::vector<bd_live_slot> slots;
+    uint64_t       next_tick = 0;       // next tick id to hand out
+    uint64_t       next_free = 0;       // oldest tick not yet released
+    std::mutex     mu;
+    std::condition_variable cv;
+    // dispatcher
+    bd_live_on_beat_fn on_beat = nullptr;
+    void          *on_beat_user = nullptr;
+    std::thread    dispatcher;
+    std::atomic<bool> stop{false};
+    int            dispatch_error = BD_OK;
+};
+
+static void bd_live_release_locked(bd_live *L, bd_live_slot &s)
+{
+    s.busy = false;
+    L->next_free = s.tick + 1;
+    L->cv.notify_all();
+}
+
+static void bd_live_dispatch_loop(bd_live *L)
+{
+    (void)hipSetDevice(L->device);
+    uint64_t tick = 0;
+    for (;;) {
+        bd_live_slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(L->mu);
+            L->cv.wait(lk, [&] { return L->stop.load() || L->next_tick > tick; });
+            if (L->next_tick <= tick) return; // stopping and nothing left
+            s = &L->slots[tick % L->depth];
+        }
+        if (hipEventSynchronize(s->done) != hipSuccess) { L->dispatch_error = BD_ERR_HIP; return; }
+        for (uint32_t m = 0; m < L->n_streams; m++)
+            if (s->h_res[m].beat) L->on_beat(L->on_beat_user, m, s->h_res[m].relative_ms);
+        {
+            std::lock_guard<std::mutex> lk(L->mu);
+            bd_live_release_locked(L, *s);
+        }
+        tick++;
+    }
+}
+
+extern "C" void bd_live_destroy(bd_live *L)
+{
+    if (!L) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && prev != L->device) (void)hipSetDevice(L->device);
+    if (L->dispatcher.joinable()) {
+        { std::lock_guard<std::mutex> lk(L->mu); L->stop = true; }
+        L->cv.notify_all();
+        L->dispatcher.join();
+    }
+    if (L->stream) (void)hipStreamSynchronize(L->stream);
+    for (auto &s : L->slots) {
+        for (auto &g : s.graphs) (void)hipGraphExecDestroy(g.second);
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.d_raw) (void)hipFree(s.d_raw);
+        if (s.d_i16) (void)hipFree(s.d_i16);
+        if (s.d_res) (void)hipFree(s.d_res);
+        if (s.h_res) (void)hipHostFree(s.h_res);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (L->d_ring) (void)hipFree(L->d_ring);
+    if (L->d_state) (void)hipFree(L->d_state);
+    if (L->stream) (void)hipStreamDestroy(L->stream);
+    if (prev >= 0 && prev != L->device) (void)hipSetDevice(prev);
+    delete L;
+}
+
+static int bd_live_init(bd_live *L)
+{
+    const size_t M = L->n_streams, cap = (size_t)L->max_len;
+    BD_HIP(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+    BD_HIP(hipMalloc((void **)&L->d_ring, M * BD_RING_LEN * sizeof(int16_t)));
+    BD_HIP(hipMalloc((void **)&L->d_state, M * sizeof(bd_live_state)));
+    BD_HIP(hipMemsetAsync(L->d_ring, 0, M * BD_RING_LEN * sizeof(int16_t), L->stream)); // spectrum.rs:50-51
+    BD_HIP(hipMemsetAsync(L->d_state, 0, M * sizeof(bd_live_state), L->stream));        // mod.rs:65-67
+    L->slots.resize(L->depth);
+    for (auto &s : L->slots) {
+        BD_HIP(hipHostMalloc(&s.h_in, M * cap * 4, hipHostMallocDefault));
+        BD_HIP(hipMalloc(&s.d_raw, M * cap * 4));
+        BD_HIP(hipMalloc((void **)&s.d_i16, M * cap * sizeof(int16_t)));
+        BD_HIP(hipMalloc((void **)&s.d_res, M * sizeof(bd_live_result)));
+        BD_HIP(hipHostMalloc((void **)&s.h_res, M * sizeof(bd_live_result), hipHostMallocDefault));
+        BD_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    BD_HIP(hipStreamSynchronize(L->stream));
+    return BD_OK;
+}
+
+extern "C" int bd_live_create(int kind, uint32_t sampling_rate, const bd_params *params,
+                              uint32_t n_streams, uint32_t max_callback_len, uint32_t depth,
+                              int device, bd_live **out)
+{
+    if (!out) { bd_set_error("bd_live_create: out is NULL"); return BD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (n_streams == 0 || max_callback_len == 0) { bd_set_error("bd_live_create: n_streams and max_callback_len must be positive"); return BD_ERR_INVALID_ARG; }
+    bd_plan plan;
+    int s = bd_make_plan(kind, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        bd_set_error("no HIP device available (this library has no CPU path)");
+        return BD_ERR_NO_DEVICE;
+    }
+    int prev = 0;
+    BD_HIP(hipGetDevice(&prev));
+    if (device < 0) device = prev;
+    if (device >= count) { bd_set_error("device %d out of range (%d devices)", device, count); return BD_ERR_INVALID_ARG; }
+    bd_live *L = new (std::nothrow) bd_live();
+    if (!L) { bd_set_error("out of host memory"); return BD_ERR_HIP; }
+    L->plan = plan; L->device = device; L->n_streams = n_streams; L->max_len = max_callback_len;
+    L->depth = depth ? (depth > 64 ? 64 : depth) : 4;
+    if (device != prev) BD_HIP(hipSetDevice(device));
+    s = bd_live_init(L);
+    if (device != prev) (void)hipSetDevice(prev);
+    if (s != BD_OK) { bd_live_destroy(L); return s; }
+    *out = L;
+    return BD_OK;
+}
+
+extern "C" int bd_live_set_on_beat(bd_live *L, bd_live_on_beat_fn cb, void *user)
+{
+    if (!L || !cb) { bd_set_error("bd_live_set_on_beat: null argument"); return BD_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->dispatcher.joinable() || L->next_tick != 0) {
+        bd_set_error("bd_live_set_on_beat: must be called once, before the first submit");
+        return BD_ERR_INVALID_ARG;
+    }
+    L->on_beat = cb; L->on_beat_user = user;
+    L->dispatcher = std::thread(bd_live_dispatch_loop, L);
+    return BD_OK;
+}
+
+// builds (captures) the graph of one tick for this slot, callback length and format
+static int bd_live_build_graph(bd_live *L, bd_live_slot &s, uint32_t n, int format, hipGraphExec_t *out)
+{
+    const size_t M = L->n_streams;
+    const size_t elem = format == BD_FMT_F32 ? 4 : 2;
+    hipGraph_t graph = nullptr;
+    BD_HIP(hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed));
+    hipError_t e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->stream);
+    const int16_t *in16 = (const int16_t *)s.d_raw;
+    if (e == hipSuccess && format != BD_FMT_I16) {
+        const uint64_t total = (uint64_t)M * n;
+        hipLaunchKernelGGL(bd_live_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L->stream,
+                           (const void *)s.d_raw, s.d_i16, total, format);
+        in16 = s.d_i16;
+    }
+    if (e == hipSuccess) {
+        bd_live_args a;
+        a.in = in16; a.in_stride = n; a.n = n;
+        a.ring = L->d_ring; a.state = L->d_state; a.result = s.d_res; a.plan = L->plan;
+        hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->stream, a);
+        e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->stream);
+    }
+    hipError_t e2 = hipStreamEndCapture(L->stream, &graph);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return bd_check_hip(e != hipSuccess ? e : e2, "capture live tick graph");
+    }
+    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    return bd_check_hip(e, "instantiate live tick graph");
+}
+
+extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int format, uint64_t *tick_id)
+{
+    if (!L || !samples) { bd_set_error("bd_live_submit: null argument"); return BD_ERR_INVALID_ARG; }
+    if (n == 0) { bd_set_error("empty window (the reference panics at window_stats.rs:51)"); return BD_ERR_EMPTY_WINDOW; }
+    if (n > L->max_len) { bd_set_error("callback of %u samples exceeds max_callback_len %u", n, L->max_len); return BD_ERR_INVALID_ARG; }
+    if (format != BD_FMT_I16 && format != BD_FMT_U16 && format != BD_FMT_F32) { bd_set_error("unknown sample format %d", format); return BD_ERR_INVALID_ARG; }
+    if (L->dispatch_error != BD_OK) { bd_set_error("live dispatcher failed"); return L->dispatch_error; }
+    uint64_t tick;
+    bd_live_slot *s;
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        tick = L->next_tick;
+        s = &L->slots[tick % L->depth];
+        if (s->busy && !L->on_beat) {
+            bd_set_error("live ring full: poll tick %llu first", (unsigned long long)s->tick);
+            return BD_ERR_UNSUPPORTED;
+        }
+        L->cv.wait(lk, [&] { return !s->busy; }); // the dispatcher frees slots
+    }
+    int prev = 0;
+    BD_HIP(hipGetDevice(&prev));
+    if (prev != L->device) BD_HIP(hipSetDevice(L->device));
+    const size_t elem = format == BD_FMT_F32 ? 4 : 2;
+    memcpy(s->h_in, samples, (size_t)L->n_streams * n * elem);
+    int st = BD_OK;
+    auto key = std::make_tuple(n, format);
+    auto it = s->graphs.find(key);
+    if (it == s->graphs.end()) {
+        hipGraphExec_t g = nullptr;
+        st = bd_live_build_graph(L, *s, n, format, &g);
+        if (st == BD_OK) it = s->graphs.emplace(key, g).first;
+    }
+    if (st == BD_OK) st = bd_check_hip(hipGraphLaunch(it->second, L->stream), "launch live tick graph");
+    if (st == BD_OK) st = bd_check_hip(hipEventRecord(s->done, L->stream), "record tick event");
+    if (prev != L->device) (void)hipSetDevice(prev);
+    if (st != BD_OK) return st;
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        s->busy = true; s->tick = tick;
+        L->next_tick = tick + 1;
+    }
+    L->cv.notify_all();
+    if (tick_id) *tick_id = tick;
+    return BD_OK;
+}
+
+extern "C" int bd_live_poll(bd_live *L, uint64_t tick_id, int wait, uint8_t *beats, uint32_t *relative_ms,
+                            float *values)
+{
+    if (!L) { bd_set_error("bd_live_poll: null handle"); return BD_ERR_INVALID_ARG; }
+    bd_live_slot *s;
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        if (tick_id >= L->next_tick) { bd_set_error("tick %llu has not been submitted", (unsigned long long)tick_id); return BD_ERR_INVALID_ARG; }
+        s = &L->slots[tick_id % L->depth];
+        if (!L->on_beat && (!s->busy || s->tick != tick_id)) { bd_set_error("tick %llu is no longer in the ring", (unsigned long long)tick_id); return BD_ERR_INVALID_ARG; }
+    }
+    if (L->on_beat) {
+        // results are delivered through the callback; poll only waits for the tick
+        std::unique_lock<std::mutex> lk(L->mu);
+        if (!wait) return L->next_free > tick_id ? 1 : 0;
+        L->cv.wait(lk, [&] { return L->next_free > tick_id || L->dispatch_error != BD_OK; });
+        return L->dispatch_error != BD_OK ? L->dispatch_error : 1;
+    }
+    if (wait) BD_HIP(hipEventSynchronize(s->done));
+    else {
+        hipError_t e = hipEventQuery(s->done);
+        if (e == hipErrorNotReady) return 0;
+        BD_HIP(e);
+    }
+    for (uint32_t m = 0; m < L->n_streams; m++) {
+        if (beats) beats[m] = (uint8_t)s->h_res[m].beat;
+        if (relative_ms) relative_ms[m] = s->h_res[m].relative_ms;
+        if (values) values[m] = s->h_res[m].value;
+    }
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        bd_live_release_locked(L, *s);
+    }
+    return 1;
+}
+
+// =============================================================================
+// record::start_listening (src/record.rs:39-149) with the cpal device replaced
+// by a caller-supplied source of callbacks.
+// =============================================================================
+struct bd_listener {
+    std::thread thread;
+    int         status = BD_OK;
+    std::string message;
+};
+
+extern "C" int bd_start_listening(bd_on_beat_fn on_beat, void *on_beat_user, const bd_input_source *source,
+                                  int kind, const volatile int *keep_recording, bd_listener **out)
+{
+    if (!out || !on_beat || !keep_recording) { bd_set_error("bd_start_listening: null argument"); return BD_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!__atomic_load_n(keep_recording, __ATOMIC_SEQ_CST)) {               // record.rs:45-47
+        bd_set_error("Variable keep_recording is false from the beginning!?");
+        return BD_ERR_STOPPED;
+    }
+    if (!source || !source->read) {                                         // record.rs:51-55
+        bd_set_error("Must have input device!");
+        return BD_ERR_NO_DEVICE;
+    }
+    if (source->sample_format != BD_FMT_I16 && source->sample_format != BD_FMT_U16 && source->sample_format != BD_FMT_F32) {
+        bd_set_error("unknown sample format %d", source->sample_format);
+        return BD_ERR_INVALID_ARG;
+    }
+    bd_live *L = nullptr;
+    const uint32_t cap = source->max_callback_len ? source->max_callback_len : 4096;
+    int s = bd_live_create(kind, source->sampling_rate, nullptr, 1, cap, 4, -1, &L); // record.rs:85 detector(sampling_rate)
+    if (s != BD_OK) return s;
+    bd_listener *h = new (std::nothrow) bd_listener();
+    if (!h) { bd_live_destroy(L); bd_set_error("out of host memory"); return BD_ERR_HIP; }
+    const bd_input_source src = *source;
+    h->thread = std::thread([=] {                                           // record.rs:87 spawn
+        std::vector<unsigned char> buf((size_t)cap * 4);
+        while (__atomic_load_n(keep_recording, __ATOMIC_SEQ_CST)) {         // record.rs:141-145
+            const size_t n = src.read(src.user, buf.data(), cap);
+            if (n == 0) break;                                              // source exhausted
+            uint64_t tick = 0;
+            int rc = bd_live_submit(L, buf.data(), (uint32_t)n, src.sample_format, &tick);
+            uint8_t beat = 0; uint32_t ms = 0;
+            if (rc == BD_OK) rc = bd_live_poll(L, tick, 1, &beat, &ms, nullptr);
+            if (rc < 0) { h->status = rc; h->message = bd_last_error(); break; }
+            if (beat) on_beat(on_beat_user, ms);                            // record.rs:95-97, on this thread
+        }
+        bd_live_destroy(L);
+    });
+    *out = h;
+    return BD_OK;
+}
+
+extern "C" int bd_listener_join(bd_listener *h)
+{
+    if (!h) return BD_ERR_INVALID_ARG;
+    if (h->thread.joinable()) h->thread.join();                             // JoinHandle::join
+    const int s = h->status;
+    if (s != BD_OK) bd_set_error("%s", h->message.c_str());
+    delete h;
+    return s;
 }

@@ -172,6 +172,60 @@ int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t call
                   uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                   uint32_t max_beats, void *hip_stream);
 
+/* ---- live path ----------------------------------------------------------- */
+/* Sample formats of an input device (cpal::SampleFormat, src/record.rs:90-133). */
+#define BD_FMT_I16 0
+#define BD_FMT_U16 1   /* converted by record::u16_data_to_i16, src/record.rs:151-158 */
+#define BD_FMT_F32 2   /* converted by record::f32_data_to_i16, src/record.rs:160-166 */
+
+/* Multi-stream live engine (new): n_streams independent detectors advanced
+ * together, one callback per stream and tick, through a ring of `depth` slots
+ * (0 = 4) of pinned staging buffers; each tick replays a captured HIP graph
+ * (copy in, convert, analyse, copy out) on one stream.  Callbacks of at most
+ * max_callback_len samples. */
+typedef struct bd_live bd_live;
+typedef void (*bd_live_on_beat_fn)(void *user, uint32_t stream, uint32_t relative_ms);
+
+int bd_live_create(int kind, uint32_t sampling_rate, const bd_params *params,
+                   uint32_t n_streams, uint32_t max_callback_len, uint32_t depth,
+                   int device, bd_live **out);
+/* Optional, before the first submit: beats are then delivered by a dispatcher
+ * thread, in tick order then stream order (the on_beat contract of
+ * src/record.rs:96 for many streams), and slots are recycled automatically. */
+int bd_live_set_on_beat(bd_live *live, bd_live_on_beat_fn on_beat, void *user);
+/* One tick: `samples` is host memory [n_streams][n] in `format`.  Returns once the
+ * tick is staged and enqueued; *tick_id numbers ticks from 0. */
+int bd_live_submit(bd_live *live, const void *samples, uint32_t n, int format, uint64_t *tick_id);
+/* Result of a tick: 1 = done (outputs filled, each [n_streams] or NULL), 0 = not
+ * finished yet (wait == 0), < 0 error.  Without an on_beat callback every tick must
+ * be polled before its slot is reused. */
+int bd_live_poll(bd_live *live, uint64_t tick_id, int wait, uint8_t *beats, uint32_t *relative_ms,
+                 float *values);
+void bd_live_destroy(bd_live *live);
+
+/* record::start_listening(on_beat_cb, input_dev, strategy, keep_recording)
+ * -> Result<JoinHandle<()>, String>, src/record.rs:39-44, with the cpal device
+ * replaced by a source of callbacks.  `read` blocks until the next callback is
+ * available, writes at most `capacity` samples of `sample_format` and returns
+ * their number (0 ends the stream).  Spawns a thread (record.rs:87) that feeds
+ * every callback to a detector and calls on_beat on that thread for every beat
+ * (record.rs:95-97) until *keep_recording becomes 0 (record.rs:141-145).
+ * Errors as the reference: BD_ERR_STOPPED if keep_recording is already false
+ * (record.rs:45-47), BD_ERR_NO_DEVICE without a source (record.rs:51-55). */
+typedef void (*bd_on_beat_fn)(void *user, uint32_t relative_ms);
+typedef struct bd_input_source {
+    uint32_t sampling_rate;      /* default_input_config().sample_rate(), record.rs:58 */
+    int      sample_format;      /* BD_FMT_*, record.rs:59 */
+    uint32_t max_callback_len;   /* 0 = 4096 */
+    size_t (*read)(void *user, void *buffer, size_t capacity);
+    void    *user;
+} bd_input_source;
+typedef struct bd_listener bd_listener;
+int bd_start_listening(bd_on_beat_fn on_beat, void *on_beat_user, const bd_input_source *source,
+                       int kind, const volatile int *keep_recording, bd_listener **out);
+/* JoinHandle::join: waits for the thread, returns its status and frees the handle. */
+int bd_listener_join(bd_listener *listener);
+
 /* ---- ingest converters, src/record.rs:151-166 (device pointers) -------- */
 int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, void *hip_stream);
 int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, void *hip_stream);

@@ -1,0 +1,160 @@
+"""The live path: multi-stream ring engine and start_listening
+(src/record.rs:39-166 of the reference) against per-stream oracle detectors."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+SR = 44100
+
+
+class ArraySource:
+    """A stand-in for a cpal input device that replays an array in callbacks of
+    the given lengths (Linux delivers "mostly 500-540" samples, spectrum.rs:40-42)."""
+
+    def __init__(self, data, lengths, sample_format, sampling_rate=SR):
+        self.data, self.lengths, self.pos, self.i = data, lengths, 0, 0
+        self.sample_format, self.sampling_rate, self.max_callback_len = sample_format, sampling_rate, 4096
+
+    def read(self, capacity):
+        if self.pos >= len(self.data):
+            return self.data[:0]
+        n = min(self.lengths[self.i % len(self.lengths)], capacity, len(self.data) - self.pos)
+        out = self.data[self.pos:self.pos + n]
+        self.pos += n
+        self.i += 1
+        return out
+
+
+def test_start_listening_errors_match_the_reference(bd):
+    # record.rs:45-47: keep_recording false from the beginning -> Err(String)
+    keep = C.c_int(0)
+    with pytest.raises(bd.BeatDetectorError) as e:
+        bd.start_listening(lambda info: None, ArraySource(np.zeros(10, np.int16), [5], bd.FMT_I16),
+                           bd.StrategyKind.Spectrum, keep)
+    assert e.value.status == -7 and "keep_recording is false from the beginning" in str(e.value)
+    # record.rs:51-55: no input device -> Err("Must have input device!")
+    keep = C.c_int(1)
+    with pytest.raises(bd.BeatDetectorError) as e:
+        bd.start_listening(lambda info: None, None, bd.StrategyKind.LPF, keep)
+    assert e.value.status == -2 and "Must have input device!" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind_name", ["Spectrum", "LPF"])
+def test_live_256_streams_match_oracle(bd, oracle, kind_name):
+    M, L, ticks = 256, 1024, 110
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    x = bd.synth_fill_host(M, L * ticks, first_stream=500, seed=77)
+    live = bd.Live(kind, SR, M, max_callback_len=L, depth=4)
+    refs = [oracle.OracleDetector(okind, SR) for _ in range(M)]
+    n_beats = 0
+    pending = []
+    for t in range(ticks):
+        pending.append((t, live.submit(x[:, t * L:(t + 1) * L])))
+        if len(pending) == 4 or t == ticks - 1:     # keep the ring full, then drain in order
+            for tt, tick in pending:
+                beats, ms, _ = live.poll(tick)
+                for m in range(M):
+                    want = refs[m].is_beat(x[m, tt * L:(tt + 1) * L])
+                    got = int(ms[m]) if beats[m] else None
+                    assert got == want, (tt, m)
+                    n_beats += want is not None
+            pending = []
+    assert n_beats > 50
+    live.close()
+
+
+@pytest.mark.gpu
+def test_live_ring_full_is_reported(bd):
+    live = bd.Live(bd.StrategyKind.LPF, SR, 2, max_callback_len=64, depth=2)
+    z = np.zeros((2, 64), dtype=np.int16)
+    t0, t1 = live.submit(z), live.submit(z)
+    with pytest.raises(bd.BeatDetectorError):
+        live.submit(z)                      # both slots hold unpolled ticks
+    assert live.poll(t0) is not None and live.poll(t1) is not None
+    live.submit(z)
+    with pytest.raises(bd.BeatDetectorError):
+        live.submit(np.zeros((2, 65), dtype=np.int16))   # longer than max_callback_len
+    live.close()
+
+
+@pytest.mark.gpu
+def test_live_on_beat_callback_order_and_formats(bd, oracle):
+    M, L, ticks = 16, 512, 200
+    x = bd.synth_fill_host(M, L * ticks, first_stream=900, seed=3)
+    for fmt in (bd.FMT_I16, bd.FMT_U16, bd.FMT_F32):
+        if fmt == bd.FMT_I16:
+            raw, as_i16 = x, x
+        elif fmt == bd.FMT_U16:
+            raw = (x.astype(np.int32) + 16383).astype(np.uint16)      # inverse of the reference's conversion
+            as_i16 = oracle.u16_data_to_i16(raw)
+        else:
+            raw = (x.astype(np.float32) / np.float32(32767.0))
+            as_i16 = oracle.f32_data_to_i16(raw)
+        got = []
+        live = bd.Live(bd.StrategyKind.Spectrum, SR, M, max_callback_len=L, depth=3,
+                       on_beat=lambda stream, info: got.append((stream, info.relative_ms())))
+        last = 0
+        for t in range(ticks):
+            last = live.submit(raw[:, t * L:(t + 1) * L], fmt)
+        live.poll(last)                       # waits until the dispatcher has delivered the last tick
+        live.close()
+        want = []
+        refs = [oracle.OracleDetector(oracle.KIND_SPECTRUM, SR) for _ in range(M)]
+        for t in range(ticks):
+            for m in range(M):
+                ms = refs[m].is_beat(as_i16[m, t * L:(t + 1) * L])
+                if ms is not None:
+                    want.append((m, ms))
+        assert got == want and len(want) > 10, fmt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt_name", ["I16", "F32", "U16"])
+def test_start_listening_delivers_the_reference_beats(bd, oracle, fmt_name):
+    fmt = getattr(bd, "FMT_" + fmt_name)
+    x = bd.synth_fill_host(1, SR * 6, first_stream=4242, seed=9)[0]
+    if fmt == bd.FMT_I16:
+        raw, as_i16 = x, x
+    elif fmt == bd.FMT_U16:
+        raw = (x.astype(np.int32) + 16383).astype(np.uint16)
+        as_i16 = oracle.u16_data_to_i16(raw)
+    else:
+        raw = x.astype(np.float32) / np.float32(32767.0)
+        as_i16 = oracle.f32_data_to_i16(raw)
+    lengths = [512, 529, 500, 540, 1024, 517]
+    src = ArraySource(raw, lengths, fmt)
+    got = []
+    keep = C.c_int(1)
+    h = bd.start_listening(lambda info: got.append(info.relative_ms()), src, bd.StrategyKind.Spectrum, keep)
+    h.join()                                  # the source ends -> the thread ends
+    ref = oracle.OracleDetector(oracle.KIND_SPECTRUM, SR)
+    want, pos, i = [], 0, 0
+    while pos < len(as_i16):
+        n = min(lengths[i % len(lengths)], len(as_i16) - pos)
+        ms = ref.is_beat(as_i16[pos:pos + n])
+        if ms is not None:
+            want.append(ms)
+        pos += n
+        i += 1
+    assert got == want and len(want) >= 3
+
+
+@pytest.mark.gpu
+def test_start_listening_stops_when_keep_recording_is_cleared(bd):
+    x = bd.synth_fill_host(1, SR * 20, first_stream=1, seed=2)[0]
+    src = ArraySource(x, [1024], bd.FMT_I16)
+    keep = C.c_int(1)
+    seen = []
+
+    def on_beat(info):
+        seen.append(info.relative_ms())
+        if len(seen) == 2:
+            keep.value = 0                    # record.rs:141-145: the loop ends once the flag is false
+
+    h = bd.start_listening(on_beat, src, bd.StrategyKind.LPF, keep)
+    h.join()
+    assert len(seen) == 2 and src.pos < len(x)
