@@ -71,6 +71,28 @@ __device__ __forceinline__ uint4 bd_load_stream16(const void *p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// Result stores.  Outputs are a trickle (0.5 % of the bytes) inside a saturated
+// read stream; written with the default policy they cost 3 - 15 % of the kernel's
+// time, depending on where the driver happened to place the sample buffer.
+// Non-temporal, write-through stores (nt sc1) remove most of that cost
+// (15.8 -> 13.8 ms in the bad placement, 13.6 -> 13.3 ms in the good one, hop-512
+// Spectrum workload).  The policy bits only exist on buffer/global instructions,
+// so stores go through a buffer descriptor over the wavefront's output range
+// [base, base + bytes): `base` must be wave-uniform.
+#define BD_AUX_STREAM_STORE 18 /* nt (2) | sc1 (16) */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bd_out_rsrc(void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bd_store_stream_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, BD_AUX_STREAM_STORE);
+}
+__device__ __forceinline__ void bd_store_stream_u8(__amdgpu_buffer_rsrc_t r, unsigned byte_off, uint8_t v)
+{
+    __builtin_amdgcn_raw_buffer_store_b8(v, r, byte_off, 0, BD_AUX_STREAM_STORE);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float bd_dpp_f(float v)
 {

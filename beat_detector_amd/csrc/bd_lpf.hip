@@ -49,19 +49,20 @@ __device__ __forceinline__ void bd_lpf_step(float x, float alpha, float &y, floa
     xmax = fmaxf(xmax, fabsf(x));
 }
 
-__device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, uint64_t j, bool valid,
+// `j0` is the first window of the wavefront's group, `rows` the number of valid lanes
+__device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, uint64_t j0, unsigned rows, int lane,
                                               float xmax, float ymax)
 {
-    if (!valid) return;
     const float wmax = fminf(xmax, 32767.f);                 // window_stats.rs:47
     const bool gate = wmax >= (float)a.min_amp;              // lib.rs:135
     // (ratio * max as f32) as i16: truncate, saturate, NaN -> 0  (lpf.rs:74)
     float thr = truncf(a.ratio * wmax);
     thr = (thr != thr) ? 0.f : fminf(fmaxf(thr, -32768.f), 32767.f);
     const bool flag = gate && (ymax >= thr);                 // lpf.rs:75
-    const uint64_t o = s * a.out_stride + j;
-    if (a.values) a.values[o] = gate ? ymax : 0.f;
-    a.flags[o] = flag ? 1 : 0;
+    const uint64_t o0 = s * a.out_stride + j0;
+    // lanes past `rows` fall outside the descriptors and are dropped
+    bd_store_stream_u8(bd_out_rsrc(a.flags + o0, rows), (unsigned)lane, flag ? 1 : 0);
+    if (a.values) bd_store_stream_f32(bd_out_rsrc(a.values + o0, rows * 4u), (unsigned)lane * 4u, gate ? ymax : 0.f);
 }
 
 // ALIGNED: callback_len % 8 == 0, stride % 8 == 0, base 16-byte aligned.
@@ -83,7 +84,6 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     const uint32_t L = a.callback_len;
     const int16_t *gp = a.samples + s * a.stride + j0 * L; // first window of the group
     const uint64_t rows = (a.n_cb - j0 < 64) ? (a.n_cb - j0) : 64;
-    const bool valid = (uint64_t)lane < rows;
     const uint32_t n_chunks = (L + BD_LPF_CHUNK - 1) / BD_LPF_CHUNK;
 
     float y = 0.f, ymax = 0.f, xmax = 0.f;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
                 bd_lpf_step((float)tile16[lane * row_i16 + i], alpha, y, ymax, xmax);
         }
     }
-    bd_lpf_finish(a, s, j0 + lane, valid, xmax, ymax);
+    bd_lpf_finish(a, s, j0, (unsigned)rows, lane, xmax, ymax);
 }
 
 __global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n_cb, uint64_t out_stride, uint64_t n)

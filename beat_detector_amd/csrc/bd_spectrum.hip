@@ -30,6 +30,7 @@
 //   a 1024-entry table.
 #include "bd_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include "bd_twiddles.inc"
 
@@ -238,13 +239,15 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint64_t cb0 = (uint64_t)(hb0 >> MODE);
-    const int n_res = n_it * (MODE == 0 ? 4 : 2);
+    const uint64_t cb_left = a.n_cb - cb0;
+    const unsigned n_res_run = (unsigned)(n_it * (MODE == 0 ? 4 : 2));
+    const unsigned n_res = cb_left < n_res_run ? (unsigned)cb_left : n_res_run; // buffer stores past it are dropped
     const uint64_t o0 = s * a.out_stride + cb0;
-    for (int i = lane; i < n_res; i += 64) {
-        if (cb0 + i < a.n_cb) {
-            if (a.values) a.values[o0 + i] = k.lds_v[i];
-            a.flags[o0 + i] = k.lds_f[i];
-        }
+    __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, n_res);
+    for (unsigned i = lane; i < n_res_run; i += 64) bd_store_stream_u8(rf, i, k.lds_f[i]);
+    if (a.values) {
+        __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values + o0, n_res * 4u);
+        for (unsigned i = lane; i < n_res_run; i += 64) bd_store_stream_f32(rv, i * 4u, k.lds_v[i]);
     }
 }
 
@@ -344,7 +347,8 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         // start; short streams still need enough wavefronts to fill 256 CUs.
         uint32_t run = 128;
         while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
-        static const int run_override = [] { const char *e = getenv("BD_SPEC_RUN"); return e ? atoi(e) : 0; }();
+        const char *run_env = getenv("BD_SPEC_RUN"); // tuning knob, read at every launch
+        const int run_override = run_env ? atoi(run_env) : 0;
         if (run_override >= 8 && run_override % 8 == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
         a.run_hbs = run;
         a.runs_per_stream = (uint32_t)((n_hb + run - 1) / run);

@@ -135,6 +135,8 @@ def main() -> None:
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    if os.environ.get("BENCH_VERBOSE"):
+        print("per-step kernel ms:", [round(e[0].elapsed_time(e[1]), 3) for e in ev], file=sys.stderr)
     k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     kernel_name = "bd_spectrum_band_kernel" if kind_name == "Spectrum" else "bd_lpf_window_kernel"
