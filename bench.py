@@ -50,6 +50,10 @@ def main() -> None:
     ap.add_argument("--seconds", type=int, default=0, help="override stream length in seconds (testing only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-streams", type=int, default=1024, help="streams in the CPU baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / timing reduction (gloo: rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (a box with one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -63,6 +67,8 @@ def main() -> None:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -70,7 +76,11 @@ def main() -> None:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     kind_name, L, streams, seconds, desc = WORKLOADS[args.workload]
     if args.streams:
@@ -143,10 +153,10 @@ def main() -> None:
     total_beats = int(count.sum().item())
 
     if dist is not None:
-        t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, k1_ms = float(t[0]), float(t[1])
-        tb = torch.tensor([total_beats], dtype=torch.int64, device=dev)
+        tb = torch.tensor([total_beats], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tb)
         total_beats = int(tb[0])
 

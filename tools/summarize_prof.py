@@ -27,6 +27,26 @@ for tag, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         for k, (v, n) in acc.items():
             lines.append(f"{k:70s} launches={n:4d} {counter}_avg={v / n:.1f}")
             traffic.setdefault(k, {})[counter] = v / n
+for f in glob.glob(os.path.join(src, "pmc_sq", "**", "*counter_collection.csv"), recursive=True):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row["Kernel_Name"][:70]
+            a = acc[k][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+    lines.append("== rocprofv3 --pmc SQ_* (per-launch averages; SQ cycle counters are in quad-cycles summed over waves/SEs) ==")
+    for k, cs in acc.items():
+        if "bd_" not in k:
+            continue
+        v = {c: x[0] / x[1] for c, x in cs.items()}
+        lines.append(f"{k:70s} " + " ".join(f"{c}={val:.4g}" for c, val in sorted(v.items())))
+        if v.get("SQ_LDS_IDX_ACTIVE"):
+            lines.append(f"{'':70s} lds_bank_conflict_share={v.get('SQ_LDS_BANK_CONFLICT', 0) / v['SQ_LDS_IDX_ACTIVE']:.4f}")
+        if v.get("SQ_WAVE_CYCLES"):
+            lines.append(f"{'':70s} valu_active_share_of_wave_cycles={v.get('SQ_ACTIVE_INST_VALU', 0) / v['SQ_WAVE_CYCLES']:.4f} "
+                         f"wait_any_share={v.get('SQ_WAIT_ANY', 0) / v['SQ_WAVE_CYCLES']:.4f}")
+        if v.get("SQ_BUSY_CYCLES"):
+            lines.append(f"{'':70s} valu_active_per_busy_cycle={v.get('SQ_ACTIVE_INST_VALU', 0) / v['SQ_BUSY_CYCLES']:.4f}")
 for j in ("bench_trace.json", "bench_fetch.json", "bench_write.json"):
     p = os.path.join(src, j)
     if os.path.exists(p):
