@@ -84,7 +84,18 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     const uint32_t L = a.callback_len;
     const int16_t *gp = a.samples + s * a.stride + j0 * L; // first window of the group
     const uint64_t rows = (a.n_cb - j0 < 64) ? (a.n_cb - j0) : 64;
-    const uint32_t n_chunks = (L + BD_LPF_CHUNK - 1) / BD_LPF_CHUNK;
+    // Chunk boundaries are placed on 128-byte lines of memory: when the rows do
+    // not start on a line (possible when callback_len % 64 == 0 makes all windows
+    // of the group equally misaligned) the first chunk is shortened to `head`
+    // samples, so that no line is fetched by two different chunks.
+    uint32_t shift = 0;
+    if (ALIGNED && (L % 64) == 0) {
+        const uint32_t head = (uint32_t)((128 - ((uintptr_t)gp & 127)) & 127) / 2;
+        if (head > 0 && head < L) shift = BD_LPF_CHUNK - head;
+    }
+    const uint32_t n_chunks = (L + shift + BD_LPF_CHUNK - 1) / BD_LPF_CHUNK;
+    auto chunk_start = [&](uint32_t ch) { const uint32_t v = ch * BD_LPF_CHUNK; return (v > shift ? v : shift) - shift; };
+    auto chunk_end = [&](uint32_t ch) { const uint32_t v = (ch + 1) * BD_LPF_CHUNK; return (v < L + shift ? v : L + shift) - shift; };
 
     float y = 0.f, ymax = 0.f, xmax = 0.f;
     const float alpha = a.alpha;
@@ -95,11 +106,12 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
         const int lrow = lane / PIECES, piece = lane % PIECES;
         uint4 stage[PIECES];
         auto load_chunk = [&](uint32_t ch) {
-            const uint32_t first = ch * BD_LPF_CHUNK + piece * 8; // sample offset inside the window
+            const uint32_t first = chunk_start(ch) + piece * 8; // sample offset inside the window
+            const uint32_t end = chunk_end(ch);
 #pragma unroll
             for (int i = 0; i < PIECES; i++) {
                 const uint32_t row = ROWS_PER_LOAD * i + lrow;
-                if (row < rows && first < L)
+                if (row < rows && first < end)
                     stage[i] = bd_load_stream16(gp + (uint64_t)row * L + first);
                 else
                     stage[i] = make_uint4(0, 0, 0, 0);
@@ -117,8 +129,7 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
             if (ch + 1 < n_chunks) load_chunk(ch + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t left = L - ch * BD_LPF_CHUNK;
-            const int pieces = left >= (uint32_t)BD_LPF_CHUNK ? PIECES : (int)(left / 8);
+            const int pieces = (int)((chunk_end(ch) - chunk_start(ch)) / 8);
             for (int p = 0; p < pieces; p++) {
                 const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
                 const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -189,7 +200,8 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0);
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
-    static const int variant_env = [] { const char *e = getenv("BD_LPF_VARIANT"); return e ? atoi(e) : 0; }();
+    const char *variant_str = getenv("BD_LPF_VARIANT");
+    const int variant_env = variant_str ? atoi(variant_str) : 0;
     const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
     const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
     const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;

@@ -318,3 +318,55 @@ def test_full_size_properties_spectrum(bd):
     n2 = l1024.values.shape[1]
     assert torch.isclose(full.values[:, 1:2 * n2:2], l1024.values, rtol=1e-5, atol=1.0).all()
     assert int(full.beat_count.sum()) > 0
+
+
+def test_tuning_knobs_do_not_change_results(bd, oracle, monkeypatch):
+    """Every value of the experiment knobs selects code that must give the same answers."""
+    x = _synth(bd, 4, SR * 10, first=60)
+    for run in ("8", "16", "64", "256", "512"):
+        monkeypatch.setenv("BD_SPEC_RUN", run)
+        for L in (512, 1024):
+            _compare(bd, oracle, "Spectrum", SR, x, L)
+    monkeypatch.delenv("BD_SPEC_RUN")
+    for variant in ("1", "2", "3"):
+        monkeypatch.setenv("BD_LPF_VARIANT", variant)
+        for L in (1024, 64, 4096, 136):
+            _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+
+
+def test_row_layouts(bd, oracle):
+    """Misaligned stream rows (16-byte aligned but not on 128-byte lines), dense and
+    padded output rows: same results."""
+    torch = _torch()
+    n = SR * 4
+    x = _synth(bd, 5, n, first=70)
+    for stride in (n, n + 8, n + 24, n + 40, ((n + 63) & ~63)):      # n = 176400 is a multiple of 16 samples
+        buf = torch.zeros((5, stride), dtype=torch.int16, device="cuda")
+        buf[:, :n] = torch.from_numpy(x).cuda()
+        for kind_name, L in (("LPF", 1024), ("LPF", 512), ("LPF", 64), ("Spectrum", 512), ("Spectrum", 1024)):
+            kind = bd.StrategyKind[kind_name]
+            okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+            n_cb = n // L
+            dense_v = torch.zeros((5, n_cb), dtype=torch.float32, device="cuda")
+            dense_f = torch.zeros((5, n_cb), dtype=torch.uint8, device="cuda")
+            bd.batch_candidates(kind, SR, buf, L, n_samples=n, values=dense_v, flags=dense_f)
+            pv, pf = bd.batch_candidates(kind, SR, buf, L, n_samples=n)
+            torch.cuda.synchronize()
+            assert torch.equal(dense_f, pf) and torch.equal(dense_v, pv)
+            _, ref_c, _ = util.oracle_batch(oracle, okind, SR, x, L)
+            np.testing.assert_array_equal(pf.cpu().numpy(), ref_c)
+    # a view that starts in the middle of a row (odd 16-byte offset)
+    buf = torch.zeros((5, n + 64), dtype=torch.int16, device="cuda")
+    buf[:, 8:8 + n] = torch.from_numpy(x).cuda()
+    view = buf[:, 8:]
+    assert view.data_ptr() % 128 == 16
+    L_ = bd.lib()
+    flags = torch.zeros((5, n // 1024), dtype=torch.uint8, device="cuda")
+    for kind_name in ("LPF", "Spectrum"):
+        okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+        rc = L_.bd_batch_candidates(bd.StrategyKind[kind_name].value, SR, None, view.data_ptr(), 5, n, n + 64, 1024,
+                                    None, flags.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        _, ref_c, _ = util.oracle_batch(oracle, okind, SR, x, 1024)
+        np.testing.assert_array_equal(flags.cpu().numpy(), ref_c)
