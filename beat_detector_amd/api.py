@@ -90,7 +90,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # BEATDET_LIB selects another build of the same library (A/B experiments)
+    return os.environ.get("BEATDET_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 def lib() -> C.CDLL:
