@@ -14,6 +14,7 @@ from .api import (  # noqa: F401
     FMT_I16,
     FMT_U16,
     Live,
+    OnsetParams,
     Params,
     Strategy,
     StrategyKind,
@@ -34,3 +35,4 @@ from .api import (  # noqa: F401
     synth_fill_host,
     u16_data_to_i16,
 )
+from .onset import OnsetResult, onset_batch, onset_frames, onset_pick, onset_stft  # noqa: F401,E402

@@ -74,6 +74,34 @@ FMT_I16, FMT_U16, FMT_F32 = 0, 1, 2
 _FMT_DTYPE = {FMT_I16: np.int16, FMT_U16: np.uint16, FMT_F32: np.float32}
 
 
+class OnsetParams(C.Structure):
+    """bd_onset_params of include/beat_detector_hip.h (extension analysis)."""
+
+    _fields_ = [
+        ("fft_len", C.c_uint32),
+        ("hop", C.c_uint32),
+        ("window", C.c_uint32),
+        ("band_max_hz", C.c_float),
+        ("mean_frames", C.c_uint32),
+        ("max_frames", C.c_uint32),
+        ("delta", C.c_float),
+        ("lambda_", C.c_float),
+        ("min_gap_ms", C.c_uint32),
+    ]
+
+    @classmethod
+    def default(cls, **overrides) -> "OnsetParams":
+        p = cls()
+        lib().bd_onset_default_params(C.byref(p))
+        if "fft_len" in overrides and "hop" not in overrides:
+            overrides["hop"] = overrides["fft_len"] // 2
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+
 class InputSource(C.Structure):
     """bd_input_source: the stand-in for a cpal input device."""
 
@@ -106,6 +134,7 @@ def lib() -> C.CDLL:
     L = C.CDLL(path)
     u32, u64, i32, vp, f32 = C.c_uint32, C.c_uint64, C.c_int, C.c_void_p, C.c_float
     pp = C.POINTER(Params)
+    op = C.POINTER(OnsetParams)
     sigs = {
         "bd_default_params": (None, [pp]),
         "bd_strerror": (C.c_char_p, [i32]),
@@ -139,6 +168,11 @@ def lib() -> C.CDLL:
         "bd_live_destroy": (None, [vp]),
         "bd_start_listening": (i32, [ON_BEAT_FN, vp, C.POINTER(InputSource), i32, C.POINTER(C.c_int), C.POINTER(vp)]),
         "bd_listener_join": (i32, [vp]),
+        "bd_onset_default_params": (None, [op]),
+        "bd_onset_frames": (u64, [u64, u32, u32]),
+        "bd_onset_stft": (i32, [u32, op, vp, u64, u64, u64, vp, vp, u64, vp]),
+        "bd_onset_pick": (i32, [u32, op, vp, u64, u64, u64, vp, vp, vp, vp, u32, vp]),
+        "bd_onset_batch": (i32, [u32, op, vp, u64, u64, u64, vp, vp, u64, vp, vp, vp, u32, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -155,7 +189,8 @@ EXPORTED_SYMBOLS = (
     "bd_batch_max_beats bd_analyze_batch bd_batch_candidates bd_analyze_batch_host "
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
-    "bd_live_destroy bd_start_listening bd_listener_join"
+    "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
+    "bd_onset_stft bd_onset_pick bd_onset_batch"
 ).split()
 
 

@@ -241,6 +241,50 @@ int bd_synth_fill_host(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                        uint64_t stream_stride, uint64_t first_stream, uint64_t seed,
                        uint32_t sampling_rate);
 
+/* ---- extension analysis: STFT onset detection --------------------------- */
+/* NO COUNTERPART IN THE REFERENCE, which keeps the three raw FFT bins up to
+ * 90 Hz of an unwindowed 1024-sample ring and compares their maximum with a
+ * constant (src/strategies/spectrum.rs:82-92).  These entry points are the
+ * windowed, hop-based version of that idea: Hann STFT (1024 or 2048 points,
+ * hop = half), energy of the band up to band_max_hz, spectral flux, onsets by
+ * adaptive-threshold peak picking.  Results are defined by the CPU definition
+ * that the tests hold (same f32 operation order: bit-identical), not by the
+ * reference.  All pointers are device pointers; calls only enqueue. */
+typedef struct bd_onset_params {
+    uint32_t fft_len;      /* 1024 or 2048 */
+    uint32_t hop;          /* fft_len / 2 */
+    uint32_t window;       /* 0 rectangular, 1 periodic Hann */
+    float    band_max_hz;  /* band energy over bins with k * fs / fft_len <= band_max_hz */
+    uint32_t mean_frames;  /* W: threshold follows the mean of flux[j-W .. j+W] */
+    uint32_t max_frames;   /* w: an onset is the maximum of flux[j-w .. j+w] */
+    float    delta;        /* threshold = delta + lambda * mean */
+    float    lambda;
+    uint32_t min_gap_ms;   /* onsets closer than this to the previous one are dropped */
+} bd_onset_params;
+void bd_onset_default_params(bd_onset_params *p);
+/* complete frames of a stream: 0 if n_samples < fft_len, else (n_samples - fft_len) / hop + 1 */
+uint64_t bd_onset_frames(uint64_t n_samples, uint32_t fft_len, uint32_t hop);
+/* flux[s * out_stride + j], band_energy[...] for every stream s and frame j
+ * (either output may be NULL; out_stride 0 = frames per stream).  Rows of
+ * `samples` must start on 16-byte boundaries. */
+int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, const int16_t *samples,
+                  uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,
+                  float *flux, float *band_energy, uint64_t out_stride, void *hip_stream);
+/* Peak picking over flux rows.  candidates ([n_streams][flux_stride], may be NULL)
+ * gets the per-frame decision before the minimum-gap rule; onset_count[s] counts
+ * every onset, onset_frame/onset_ms ([n_streams][max_onsets], may be NULL) keep
+ * the first max_onsets.  Time of frame j: ((j * hop + fft_len / 2) * 1000) / fs. */
+int bd_onset_pick(uint32_t sampling_rate, const bd_onset_params *p, const float *flux,
+                  uint64_t n_streams, uint64_t n_frames, uint64_t flux_stride,
+                  uint8_t *candidates, uint32_t *onset_count, uint32_t *onset_frame,
+                  uint32_t *onset_ms, uint32_t max_onsets, void *hip_stream);
+/* bd_onset_stft followed by bd_onset_pick on the same stream. */
+int bd_onset_batch(uint32_t sampling_rate, const bd_onset_params *p, const int16_t *samples,
+                   uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,
+                   float *flux, float *band_energy, uint64_t out_stride,
+                   uint32_t *onset_count, uint32_t *onset_frame, uint32_t *onset_ms,
+                   uint32_t max_onsets, void *hip_stream);
+
 /* ---- instrumentation --------------------------------------------------- */
 /* Name and grid of the dominant kernel of the last bd_analyze_batch call on
  * this thread (for profilers). */

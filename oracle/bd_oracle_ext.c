@@ -1,0 +1,223 @@
+/*
+ * Definition of the extension onset analysis on the CPU.  TEST INFRASTRUCTURE
+ * ONLY; NO REFERENCE COUNTERPART (see bd_oracle_ext.h).
+ *
+ * Arithmetic specification (all f32; compile with -ffp-contract=off so that the
+ * only fused operations are the fmaf calls written below):
+ *
+ * 1. Frame of N real samples x[i] (i16 converted exactly to f32), periodic Hann
+ *    window w[i] = fma(-0.5, c, 0.5) with c = BD_EXT_TW<N>[i <= N/2 ? i : N - i][0]
+ *    (= cos(2 pi i / N)), or w = 1: u[i] = w[i] * x[i].
+ * 2. Complex sequence z[n] = (u[2n], u[2n+1]), n < M = N/2.
+ * 3. Radix-2 decimation-in-time FFT of z: bit-reversal permutation, then stages
+ *    s = 1 .. log2 M.  Butterfly on (a, b) with twiddle (wr, wi) =
+ *    (cos, -sin)(2 pi j / 2^s) taken from BD_EXT_TW<N>[j * N / 2^s]:
+ *        stage 1:  t = b
+ *        stage 2:  t = b for j = 0,  t = (b.im, -b.re) for j = 1
+ *        stage >= 3:  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
+ *        a' = a + t,  b' = a - t
+ * 4. Real-input post-processing, k = 0 .. M, with P = Z[k mod M], Q = Z[(M - k) mod M],
+ *    (c, s) = BD_EXT_TW<N>[k]:
+ *        er = 0.5 * (P.re + Q.re)      ei = 0.5 * (P.im - Q.im)
+ *        dr = 0.5 * (P.re - Q.re)      di = 0.5 * (P.im + Q.im)
+ *        pr = fma(s, di, c * dr)       qi = fma(-s, dr, c * di)
+ *        X.re = er + qi                X.im = ei - pr
+ *        mag[k] = sqrt(fma(X.re, X.re, X.im * X.im))
+ * 5. Sums over bins (flux, band energy) are taken as 64 interleaved partial sums
+ *    (partial l adds the terms of k = l, l + 64, ... in ascending order, the term of
+ *    k = M last into partial 0) combined by the butterfly p[l] += p[l ^ o],
+ *    o = 32, 16, 8, 4, 2, 1.
+ *        flux[j] = sum_k max(0, mag_j[k] - mag_{j-1}[k])      (mag_{-1} = 0)
+ *        band_energy[j] = sum_{k <= kmax} mag_j[k]^2            (terms fma-free: m * m)
+ */
+#include "bd_oracle_ext.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bd_ext_tables.inc"
+
+void bdo_onset_default_params(bdo_onset_params *p)
+{
+    p->fft_len = 2048;
+    p->hop = 1024;
+    p->window = 1;
+    p->band_max_hz = 90.0f;
+    p->mean_frames = 8;
+    p->max_frames = 3;
+    p->delta = 0.0f;
+    p->lambda = 1.5f;
+    p->min_gap_ms = 100;
+}
+
+size_t bdo_onset_frames(size_t n_samples, uint32_t fft_len, uint32_t hop)
+{
+    if (hop == 0 || n_samples < fft_len) return 0;
+    return (n_samples - fft_len) / hop + 1;
+}
+
+uint32_t bdo_onset_frame_ms(size_t j, uint32_t fft_len, uint32_t hop, uint32_t sampling_rate)
+{
+    return (uint32_t)((((uint64_t)j * hop + fft_len / 2) * 1000u) / sampling_rate);
+}
+
+static const float (*tw_table(uint32_t n))[2]
+{
+    return n == 1024 ? BD_EXT_TW1024 : BD_EXT_TW2048;
+}
+
+static int log2u(uint32_t v) { int r = 0; while ((1u << r) < v) r++; return r; }
+
+int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
+{
+    if (n != 1024 && n != 2048) return -1;
+    const float (*tw)[2] = tw_table(n);
+    const uint32_t m = n / 2;
+    const int lg = log2u(m);
+    float *re = (float *)malloc(sizeof(float) * m), *im = (float *)malloc(sizeof(float) * m);
+    for (uint32_t i = 0; i < m; i++) {
+        uint32_t r = 0;
+        for (int b = 0; b < lg; b++) if (i & (1u << b)) r |= 1u << (lg - 1 - b);
+        float u0 = (float)frame[2 * i], u1 = (float)frame[2 * i + 1];
+        if (window) {
+            const uint32_t i0 = 2 * i, i1 = 2 * i + 1;
+            const float w0 = fmaf(-0.5f, tw[i0 <= m ? i0 : n - i0][0], 0.5f);
+            const float w1 = fmaf(-0.5f, tw[i1 <= m ? i1 : n - i1][0], 0.5f);
+            u0 = w0 * u0; u1 = w1 * u1;
+        }
+        re[r] = u0; im[r] = u1;
+    }
+    for (int s = 1; s <= lg; s++) {
+        const uint32_t len = 1u << s, half = len >> 1;
+        for (uint32_t base = 0; base < m; base += len) {
+            for (uint32_t j = 0; j < half; j++) {
+                const uint32_t a = base + j, b = a + half;
+                float tr, ti;
+                if (s == 1) { tr = re[b]; ti = im[b]; }
+                else if (s == 2) { if (j == 0) { tr = re[b]; ti = im[b]; } else { tr = im[b]; ti = -re[b]; } }
+                else {
+                    const float wr = tw[j * (n >> s)][0], wi = -tw[j * (n >> s)][1];
+                    const float p0 = re[b] * wr, p1 = re[b] * wi;
+                    tr = fmaf(-im[b], wi, p0);
+                    ti = fmaf(im[b], wr, p1);
+                }
+                const float ar = re[a], ai = im[a];
+                re[a] = ar + tr; im[a] = ai + ti;
+                re[b] = ar - tr; im[b] = ai - ti;
+            }
+        }
+    }
+    for (uint32_t k = 0; k <= m; k++) {
+        const uint32_t kp = k % m, kq = (m - k) % m;
+        const float c = tw[k][0], s = tw[k][1];
+        const float er = 0.5f * (re[kp] + re[kq]), ei = 0.5f * (im[kp] - im[kq]);
+        const float dr = 0.5f * (re[kp] - re[kq]), di = 0.5f * (im[kp] + im[kq]);
+        const float cdr = c * dr, cdi = c * di;
+        const float pr = fmaf(s, di, cdr), qi = fmaf(-s, dr, cdi);
+        const float xr = er + qi, xi = ei - pr;
+        const float xi2 = xi * xi;
+        mag[k] = sqrtf(fmaf(xr, xr, xi2));
+    }
+    free(re); free(im);
+    return 0;
+}
+
+int bdo_ext_rfft_mag_f64(const int16_t *frame, uint32_t n, uint32_t window, double *mag)
+{
+    if (n != 1024 && n != 2048) return -1;
+    const double pi = 3.14159265358979323846;
+    for (uint32_t k = 0; k <= n / 2; k++) {
+        double r = 0.0, i = 0.0;
+        for (uint32_t t = 0; t < n; t++) {
+            const double w = window ? 0.5 - 0.5 * cos(2.0 * pi * t / n) : 1.0;
+            const double a = -2.0 * pi * (double)((uint64_t)k * t % n) / n;
+            r += w * frame[t] * cos(a);
+            i += w * frame[t] * sin(a);
+        }
+        mag[k] = sqrt(r * r + i * i);
+    }
+    return 0;
+}
+
+/* 64 interleaved partial sums + xor butterfly (item 5 of the specification) */
+static float lane_sum(const float *term, uint32_t m /* terms for k = 0 .. m */)
+{
+    float p[64];
+    for (int l = 0; l < 64; l++) {
+        float s = 0.0f;
+        for (uint32_t k = (uint32_t)l; k < m; k += 64) s += term[k];
+        p[l] = s;
+    }
+    p[0] += term[m];
+    for (int o = 32; o >= 1; o >>= 1) {
+        float q[64];
+        for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ o];
+        memcpy(p, q, sizeof(p));
+    }
+    return p[0];
+}
+
+int bdo_onset_stft(const int16_t *samples, size_t n_samples, uint32_t sampling_rate,
+                   const bdo_onset_params *p, float *flux, float *band_energy)
+{
+    const uint32_t n = p->fft_len, m = n / 2;
+    if ((n != 1024 && n != 2048) || p->hop != n / 2) return -1;
+    const size_t frames = bdo_onset_frames(n_samples, n, p->hop);
+    float *prev = (float *)calloc(m + 1, sizeof(float)), *cur = (float *)malloc((m + 1) * sizeof(float));
+    float *term = (float *)malloc((m + 1) * sizeof(float));
+    /* bins of the band: k * (fs / N) <= band_max_hz, f32 as in the Spectrum strategy */
+    const float res = (float)sampling_rate / (float)n;
+    uint32_t kmax = 0;
+    for (uint32_t k = 0; k <= m; k++) { if ((float)k * res <= p->band_max_hz) kmax = k; else break; }
+    for (size_t j = 0; j < frames; j++) {
+        bdo_ext_rfft_mag(samples + j * p->hop, n, p->window, cur);
+        if (flux) {
+            for (uint32_t k = 0; k <= m; k++) { const float d = cur[k] - prev[k]; term[k] = d > 0.0f ? d : 0.0f; }
+            flux[j] = lane_sum(term, m);
+        }
+        if (band_energy) {
+            for (uint32_t k = 0; k <= m; k++) term[k] = k <= kmax ? cur[k] * cur[k] : 0.0f;
+            band_energy[j] = lane_sum(term, m);
+        }
+        float *t = prev; prev = cur; cur = t;
+    }
+    free(prev); free(cur); free(term);
+    return 0;
+}
+
+size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate,
+                      const bdo_onset_params *p, uint8_t *candidates,
+                      uint32_t *onset_frame, uint32_t *onset_ms, size_t max_onsets)
+{
+    size_t count = 0;
+    uint32_t last_ms = 0;
+    int have_last = 0;
+    for (size_t j = 0; j < n_frames; j++) {
+        const size_t lo = j > p->mean_frames ? j - p->mean_frames : 0;
+        const size_t hi = j + p->mean_frames < n_frames - 1 ? j + p->mean_frames : n_frames - 1;
+        float sum = 0.0f;
+        for (size_t i = lo; i <= hi; i++) sum += flux[i];
+        const float mean = sum / (float)(hi - lo + 1);
+        const float thr = fmaf(p->lambda, mean, p->delta);
+        const size_t mlo = j > p->max_frames ? j - p->max_frames : 0;
+        const size_t mhi = j + p->max_frames < n_frames - 1 ? j + p->max_frames : n_frames - 1;
+        int is_max = 1;
+        for (size_t i = mlo; i <= mhi; i++) {
+            if (i < j && flux[i] >= flux[j]) is_max = 0;   /* ties: the earliest frame wins */
+            if (i > j && flux[i] > flux[j]) is_max = 0;
+        }
+        const int cand = is_max && flux[j] > thr;
+        if (candidates) candidates[j] = (uint8_t)cand;
+        if (!cand) continue;
+        const uint32_t ms = bdo_onset_frame_ms(j, p->fft_len, p->hop, sampling_rate);
+        if (have_last && ms < last_ms + p->min_gap_ms) continue;
+        have_last = 1; last_ms = ms;
+        if (count < max_onsets) {
+            if (onset_frame) onset_frame[count] = (uint32_t)j;
+            if (onset_ms) onset_ms[count] = ms;
+        }
+        count++;
+    }
+    return count;
+}

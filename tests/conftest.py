@@ -43,3 +43,10 @@ def bd():
     import beat_detector_amd
     beat_detector_amd.lib()
     return beat_detector_amd
+
+
+@pytest.fixture(scope="session")
+def oracle_ext():
+    from oracle import bd_oracle_ext
+    bd_oracle_ext.lib()
+    return bd_oracle_ext

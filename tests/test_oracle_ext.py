@@ -1,0 +1,97 @@
+"""CPU tests of the definition of the extension onset analysis (oracle/bd_oracle_ext.c).
+
+The reference computes none of this, so there is no reference vector to pin it
+to: the f32 spectrum is checked against numpy's float64 FFT and against the
+definition's own float64 evaluation, the rest against hand-computed cases.
+"""
+import numpy as np
+import pytest
+
+from tests.util import click_track
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+@pytest.mark.parametrize("window", [0, 1])
+def test_spectrum_matches_float64_fft(oracle_ext, n, window):
+    rng = np.random.default_rng(n + window)
+    for amp in (30000, 300, 3):
+        x = rng.integers(-amp, amp + 1, n).astype(np.int16)
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n) if window else np.ones(n)
+        want = np.abs(np.fft.rfft(x.astype(np.float64) * w))
+        got = oracle_ext.rfft_mag(x, bool(window)).astype(np.float64)
+        scale = np.sqrt(np.sum((x * w) ** 2))  # rounding noise is relative to the frame's energy
+        assert np.max(np.abs(got - want)) <= 2e-6 * scale
+        own = oracle_ext.rfft_mag_f64(x, bool(window))
+        assert np.max(np.abs(own - want)) <= 1e-9 * scale
+
+
+def test_pure_tone_lands_in_its_bin(oracle_ext):
+    n, k = 2048, 37
+    x = np.round(20000 * np.cos(2 * np.pi * k * np.arange(n) / n)).astype(np.int16)
+    mag = oracle_ext.rfft_mag(x, True)
+    # Hann: half of the amplitude * n / 2 in bin k, a quarter in k +- 1, nothing elsewhere
+    assert abs(mag[k] - 20000 * n / 4) < 1e-3 * mag[k]
+    assert abs(mag[k - 1] - 20000 * n / 8) < 1e-3 * mag[k]
+    assert np.all(np.delete(mag, [k - 1, k, k + 1]) < 1e-4 * mag[k])
+
+
+def test_frames_and_time_stamps(oracle_ext):
+    assert oracle_ext.frames(2047, 2048, 1024) == 0
+    assert oracle_ext.frames(2048, 2048, 1024) == 1
+    assert oracle_ext.frames(3071, 2048, 1024) == 1
+    assert oracle_ext.frames(3072, 2048, 1024) == 2
+    assert oracle_ext.frames(44100 * 300, 2048, 1024) == 12918
+    assert oracle_ext.frame_ms(0, 2048, 1024, 44100) == 23      # 1024 * 1000 / 44100
+    assert oracle_ext.frame_ms(43, 2048, 1024, 44100) == 1021   # (43 * 1024 + 1024) * 1000 / 44100
+
+
+def test_silence_and_constant_have_no_flux(oracle_ext):
+    z = np.zeros(8192, dtype=np.int16)
+    flux, band = oracle_ext.onset_stft(z, 44100)
+    assert flux.shape == (7,) and not flux.any() and not band.any()
+    c = np.full(8192, 1000, dtype=np.int16)
+    flux, band = oracle_ext.onset_stft(c, 44100)
+    assert flux[0] > 0 and np.all(flux[1:] == 0.0)           # the spectrum never changes after frame 0
+    assert np.all(band == band[0]) and band[0] > 0
+
+
+def test_band_energy_is_the_low_bins(oracle_ext):
+    x = click_track(2048 * 4, 11)
+    p = oracle_ext.default_params()
+    _, band = oracle_ext.onset_stft(x, 44100, p)
+    # bins with k * 44100 / 2048 <= 90 Hz: 0 .. 4
+    mag = oracle_ext.rfft_mag(x[1024:3072], True).astype(np.float64)
+    assert abs(band[1] - np.sum(mag[:5] ** 2)) <= 1e-5 * band[1]
+    p48 = oracle_ext.default_params(fft_len=1024)
+    _, band = oracle_ext.onset_stft(x, 48000, p48)
+    mag = oracle_ext.rfft_mag(x[512:1536], True).astype(np.float64)
+    assert abs(band[1] - np.sum(mag[:2] ** 2)) <= 1e-5 * band[1]   # 46.9 Hz per bin: bins 0, 1
+
+
+def test_peak_picking_known_answer(oracle_ext):
+    p = oracle_ext.default_params(mean_frames=2, max_frames=1, delta=0.5, lambda_=1.0, min_gap_ms=0)
+    flux = np.array([0, 0, 5, 0, 0, 0, 3, 3, 0, 0, 0.4, 0], dtype=np.float32)
+    cand, frame, ms = oracle_ext.onset_pick(flux, 44100, p)
+    # j=2: mean(0,0,5,0,0)=1 -> thr 1.5 < 5, local max.  j=6: mean(0,0,3,3,0)=1.2, tie with j=7: earliest wins.
+    # j=10: mean(0,0,.4,0)=.1 -> thr .6 > .4: rejected by the threshold.
+    assert cand.tolist() == [0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0]
+    assert frame.tolist() == [2, 6]
+    assert ms.tolist() == [oracle_ext.frame_ms(2, 2048, 1024, 44100), oracle_ext.frame_ms(6, 2048, 1024, 44100)]
+    # minimum gap: frames are 23.2 ms apart, frame 6 is 93 ms after frame 2
+    p.min_gap_ms = 100
+    _, frame, _ = oracle_ext.onset_pick(flux, 44100, p)
+    assert frame.tolist() == [2]
+    p.min_gap_ms = 93
+    _, frame, _ = oracle_ext.onset_pick(flux, 44100, p)
+    assert frame.tolist() == [2, 6]
+
+
+def test_clicks_are_found(oracle_ext):
+    sr, period = 44100, 22050
+    x = click_track(sr * 10, 5, sr=sr, period=period, noise=200)
+    flux, _ = oracle_ext.onset_stft(x, sr)
+    _, frame, ms = oracle_ext.onset_pick(flux, sr)
+    assert 18 <= len(ms) <= 21
+    gaps = np.diff(ms.astype(np.int64))
+    # frame 0 is compared with silence, so its flux is its whole spectrum: skip the first gap
+    assert np.all(np.abs(gaps[1:] - 500) <= 47)  # one hop is 23 ms
