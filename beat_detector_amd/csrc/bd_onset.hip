@@ -42,6 +42,8 @@ struct bd_onset_args {
 
 #define BD_ONSET_MAX_RUN 128
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int E> struct bd_fft_cfg {
     static constexpr int LGE = (E == 16) ? 4 : 3;
     static constexpr int M = 64 * E;           // complex points
@@ -50,17 +52,28 @@ template <int E> struct bd_fft_cfg {
     static constexpr int NS1 = LGE;            // stages per phase
     static constexpr int NS2 = (E == 16) ? 4 : 3;
     static constexpr int NS3 = (LGE + 6) - NS1 - NS2;
-    static constexpr int DATA_LEN = M + (M >> LGE);             // padded complex tile
-    static constexpr int TW_LEN = (N / 2 + 1) + ((N / 2 + 1) >> 5) + 1;
+    // Complex tile of one wavefront.  Point p of the transform lives at p + (p >> PADSH):
+    // with one pad slot per 32 points (N = 2048) the three access patterns -- 16
+    // consecutive points per lane, points 16 apart per lane, points 64 apart per lane --
+    // are all free of bank conflicts (the second needs the lane order of phase 2 below);
+    // N = 1024 pads every 8 points, which leaves a few two-way conflicts in phase 3.
+    // The exchange with the mirror bin M - k uses the plain index and one more slot (Z[M] := Z[0]).
+    static constexpr int PADSH = (E == 16) ? 5 : 3;
+    static constexpr int DATA_LEN = M + (M >> PADSH) + 1;
+    static constexpr int ROW3 = 64 + (64 >> PADSH);  // padded distance of points 64 apart
 };
 
-template <int E> __device__ __forceinline__ int bd_pad_d(int p) { return p + (p >> bd_fft_cfg<E>::LGE); }
-__device__ __forceinline__ int bd_pad_t(int i) { return i + (i >> 5); }
-
-template <int E> __device__ __forceinline__ float2 bd_tw_global(int idx)
+// (cos, -sin)(2 pi idx / N): the butterfly twiddle
+template <int E> __device__ __forceinline__ v2f bd_tw_fwd(int idx)
 {
-    if (E == 16) return make_float2(BD_EXT_TW2048[idx][0], BD_EXT_TW2048[idx][1]);
-    return make_float2(BD_EXT_TW1024[idx][0], BD_EXT_TW1024[idx][1]);
+    if (E == 16) return v2f{BD_EXT_TW2048[idx][0], -BD_EXT_TW2048[idx][1]};
+    return v2f{BD_EXT_TW1024[idx][0], -BD_EXT_TW1024[idx][1]};
+}
+// (cos, sin)(2 pi idx / N)
+template <int E> __device__ __forceinline__ v2f bd_tw_cs(int idx)
+{
+    if (E == 16) return v2f{BD_EXT_TW2048[idx][0], BD_EXT_TW2048[idx][1]};
+    return v2f{BD_EXT_TW1024[idx][0], BD_EXT_TW1024[idx][1]};
 }
 
 __device__ __forceinline__ int bd_rev_bits(int v, int bits)
@@ -68,215 +81,291 @@ __device__ __forceinline__ int bd_rev_bits(int v, int bits)
     return (int)(__builtin_bitreverse32((unsigned)v) >> (32 - bits));
 }
 
-// general butterfly: t = w * b with w = (c, -s); a' = a + t, b' = a - t
-__device__ __forceinline__ void bd_bfly(float &ar, float &ai, float &br, float &bi, float c, float s)
+// Packed-f32 helpers.  The VOP3P source modifiers (op_sel picks the half of a
+// register pair, neg_lo / neg_hi negate one half) make a complex multiply two
+// instructions and every butterfly four; the compiler does not form them from
+// vector shuffles, hence the inline assembly.  All are single IEEE operations
+// per half, in the order the arithmetic specification gives.
+//
+// t = w * b with w = (wr, wi):  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
+__device__ __forceinline__ v2f bd_cmul(v2f b, v2f w)
 {
-    const float wi = -s;
-    const float p0 = br * c, p1 = br * wi;
-    const float tr = __builtin_fmaf(-bi, wi, p0);
-    const float ti = __builtin_fmaf(bi, c, p1);
-    const float xr = ar, xi = ai;
-    ar = xr + tr; ai = xi + ti;
-    br = xr - tr; bi = xi - ti;
+    v2f p, t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(b), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(b), "v"(w), "v"(p));
+    return t;
+}
+__device__ __forceinline__ void bd_bfly(v2f &a, v2f &b, v2f t)
+{
+    const v2f x = a;
+    a = x + t;
+    b = x - t;
+}
+// butterfly with t = (b.im, -b.re)  (twiddle (0, -1))
+__device__ __forceinline__ void bd_bfly_rot(v2f &a, v2f &b)
+{
+    v2f ra, rb;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(ra) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(rb) : "v"(a), "v"(b));
+    a = ra; b = rb;
+}
+// Real-input post-processing of one bin (spectrum at twice its value):
+// z = Z[k], q = Z[M - k], cs = (cos, sin)(2 pi k / N); returns (Y.re, Y.im)
+__device__ __forceinline__ v2f bd_post_bin(v2f z, v2f q, v2f cs)
+{
+    v2f e, d, u, pq, y;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(e) : "v"(z), "v"(q));                 // (zr + qr, zi - qi)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(z), "v"(q));                 // (zr - qr, zi + qi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(u) : "v"(cs), "v"(d));             // (c dr, c di)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+        : "=v"(pq) : "v"(cs), "v"(d), "v"(u));                                              // (fma(s,di,c dr), fma(-s,dr,c di))
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(y) : "v"(e), "v"(pq)); // (er + qi, ei - pr)
+    return y;
 }
 
-// NS radix-2 stages on CNT = 2^NS points held in registers; point i has global
-// index base + i * 2^S0 and `lowj` = base mod 2^S0.  Global stage s = S0 + t + 1.
-template <int E, int NS, int S0, int STRIDE>
-__device__ __forceinline__ void bd_fft_stages(float *zr, float *zi, int lowj, const float2 *tw_lds)
+// Stages of the first phase (twiddle indices known at compile time).  Point q of
+// the lane, global stage s = t + 1; twiddles (1,0) and (0,-1) take the shortcut.
+template <int E>
+__device__ __forceinline__ void bd_fft_phase1(v2f *z)
 {
-    constexpr int CNT = 1 << NS;
-    constexpr int LGN = bd_fft_cfg<E>::LGN;
+    using C = bd_fft_cfg<E>;
 #pragma unroll
-    for (int t = 0; t < NS; t++) {
-        constexpr int dummy = 0; (void)dummy;
-        const int s = S0 + t + 1;
+    for (int t = 0; t < C::NS1; t++) {
 #pragma unroll
-        for (int i = 0; i < CNT; i++) {
+        for (int i = 0; i < E; i++) {
             if (i & (1 << t)) continue;
-            const int ia = i * STRIDE, ib = (i + (1 << t)) * STRIDE;
-            const int jl = i & ((1 << t) - 1);
-            if (S0 == 0 && s == 1) {
-                const float xr = zr[ia], xi = zi[ia], tr = zr[ib], ti = zi[ib];
-                zr[ia] = xr + tr; zi[ia] = xi + ti; zr[ib] = xr - tr; zi[ib] = xi - ti;
-            } else if (S0 == 0 && s == 2) {
-                const float xr = zr[ia], xi = zi[ia];
-                const float tr = jl == 0 ? zr[ib] : zi[ib];
-                const float ti = jl == 0 ? zi[ib] : -zr[ib];
-                zr[ia] = xr + tr; zi[ia] = xi + ti; zr[ib] = xr - tr; zi[ib] = xi - ti;
-            } else if (S0 == 0) {
-                const float2 w = bd_tw_global<E>(jl << (LGN - s)); // compile-time constant
-                bd_bfly(zr[ia], zi[ia], zr[ib], zi[ib], w.x, w.y);
-            } else {
-                const int j = lowj + (jl << S0);
-                const float2 w = tw_lds[bd_pad_t(j << (LGN - s))];
-                bd_bfly(zr[ia], zi[ia], zr[ib], zi[ib], w.x, w.y);
-            }
+            const int ib = i + (1 << t);
+            const int idx = (i & ((1 << t) - 1)) << (C::LGN - (t + 1));
+            v2f tv;
+            if (idx == 0) tv = z[ib];
+            else if (idx == C::N / 4) { bd_bfly_rot(z[i], z[ib]); continue; }
+            else tv = bd_cmul(z[ib], bd_tw_fwd<E>(idx));
+            bd_bfly(z[i], z[ib], tv);
         }
     }
 }
 
-__device__ __forceinline__ float bd_xor_tree_sum(float p)
+// NS stages on 2^NS points in registers (stride STRIDE in the array), twiddles
+// tw[(1 << t) - 1 + jl] prepared per lane.
+template <int NS, int STRIDE>
+__device__ __forceinline__ void bd_fft_phase(v2f *z, const v2f *tw)
 {
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) p = p + __shfl_xor(p, o, 64);
+    for (int t = 0; t < NS; t++) {
+#pragma unroll
+        for (int i = 0; i < (1 << NS); i++) {
+            if (i & (1 << t)) continue;
+            const int ia = i * STRIDE, ib = (i + (1 << t)) * STRIDE;
+            const v2f tv = bd_cmul(z[ib], tw[(1 << t) - 1 + (i & ((1 << t) - 1))]);
+            bd_bfly(z[ia], z[ib], tv);
+        }
+    }
+}
+
+// Correctly rounded square root of x >= 2^-96.  v_sqrt_f32 is within one ulp
+// for normal arguments: choose among the result and its two neighbours by the
+// sign of the exact residuals.
+__device__ __forceinline__ float bd_sqrt_rn_normal(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const int si = __builtin_bit_cast(int, s);
+    const float sd = __builtin_bit_cast(float, si - 1), su = __builtin_bit_cast(float, si + 1);
+    float vd, vu; // x - sd * s, x - su * s (assembly keeps the negation a source modifier of a scalar fma)
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vd) : "v"(sd), "v"(s), "v"(x));
+    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vu) : "v"(su), "v"(s), "v"(x));
+    return __builtin_bit_cast(float, si - 1 + (vd > 0.f ? 1 : 0) + (vu > 0.f ? 1 : 0));
+}
+
+// Sum over the wavefront as the butterfly p[l] += p[l ^ o], o = 1, 2, 4, 8, 16, 32,
+// on the DPP network; the total is valid in lane 63.  After the steps o = 1, 2 all
+// lanes of a quad agree, so the mirror patterns (l ^ 7, l ^ 15) deliver the same
+// values as l ^ 4, l ^ 8; the row broadcasts add row r - 1 into rows 1, 3 and
+// rows 0 - 1 into row 3.
+__device__ __forceinline__ float bd_butterfly_sum_lane63(float p)
+{
+    p = p + bd_dpp_f<0xB1>(p);  // quad_perm [1,0,3,2]
+    p = p + bd_dpp_f<0x4E>(p);  // quad_perm [2,3,0,1]
+    p = p + bd_dpp_f<0x141>(p); // row_half_mirror
+    p = p + bd_dpp_f<0x140>(p); // row_mirror
+    p = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x142, 0xa, 0xf, true)); // row_bcast:15 -> rows 1, 3
+    p = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x143, 0xc, 0xf, true)); // row_bcast:31 -> rows 2, 3
     return p;
+}
+
+__device__ __forceinline__ void bd_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int E>
 __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
 {
     using C = bd_fft_cfg<E>;
-    constexpr int M = C::M, LGE = C::LGE;
-    __shared__ float2 tw_lds[C::TW_LEN];
-    __shared__ float2 tile_all[4][C::DATA_LEN];
+    constexpr int M = C::M, LGE = C::LGE, N = C::N, LGN = C::LGN;
+    __shared__ v2f tile_all[4][C::DATA_LEN];
+    __shared__ v2f win_lds[E][64];   // window at samples 2 n, 2 n + 1 of point n = slot q of a lane
     __shared__ float out_lds[4][2][BD_ONSET_MAX_RUN];
-
-    for (int i = threadIdx.x; i <= C::N / 2; i += 256) tw_lds[bd_pad_t(i)] = bd_tw_global<E>(i);
-    __syncthreads();
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float2 *tile = tile_all[wave];
+    const int r6 = bd_rev_bits(lane, 6);
+    for (int q = wave; q < E; q += 4) {
+        const int nq = bd_rev_bits(q, LGE) * 64 + r6;
+        const int i0 = 2 * nq, i1 = i0 + 1;
+        v2f w;
+        w.x = __builtin_fmaf(-0.5f, bd_tw_cs<E>(i0 <= M ? i0 : N - i0).x, 0.5f);
+        w.y = __builtin_fmaf(-0.5f, bd_tw_cs<E>(i1 <= M ? i1 : N - i1).x, 0.5f);
+        win_lds[q][lane] = a.window ? w : v2f{1.f, 1.f};
+    }
+    __syncthreads();
+    v2f *tile = tile_all[wave];
     const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint64_t f0 = (task - s * a.runs_per_stream) * a.run_frames;
     const uint64_t f_end = f0 + a.run_frames < a.n_frames ? f0 + a.run_frames : a.n_frames;
     const int16_t *sp = a.samples + s * a.stride;
-    const int r6 = bd_rev_bits(lane, 6);
 
-    // slot q of this lane holds complex point n_q = rev(q) * 64 + rev6(lane) of the frame
-    int nq[E];
-    float w0[E], w1[E]; // window at samples 2 n_q and 2 n_q + 1
+    // per-lane twiddles of the second and third phase and of the post-processing
+    constexpr int S2 = C::NS1, S3 = C::NS1 + C::NS2, CNT2 = 1 << C::NS2, CNT3 = 1 << C::NS3, GROUPS = E / CNT3;
+    const int low = lane & ((1 << S2) - 1);
+    // group of phase 2: lanes 16 apart take groups two apart (N = 2048), see bd_fft_cfg
+    const int high = E == 16 ? ((lane >> 4) & 1) * 2 + (lane >> 5) : lane >> S2;
+    v2f tw2[CNT2 - 1], tw3[GROUPS][CNT3 - 1], twp[E];
 #pragma unroll
-    for (int q = 0; q < E; q++) {
-        nq[q] = bd_rev_bits(q, LGE) * 64 + r6;
-        if (a.window) {
-            const int i0 = 2 * nq[q], i1 = i0 + 1;
-            w0[q] = __builtin_fmaf(-0.5f, tw_lds[bd_pad_t(i0 <= M ? i0 : C::N - i0)].x, 0.5f);
-            w1[q] = __builtin_fmaf(-0.5f, tw_lds[bd_pad_t(i1 <= M ? i1 : C::N - i1)].x, 0.5f);
-        } else {
-            w0[q] = 1.f; w1[q] = 1.f;
-        }
-    }
+    for (int t = 0; t < C::NS2; t++)
+#pragma unroll
+        for (int jl = 0; jl < (1 << t); jl++)
+            tw2[(1 << t) - 1 + jl] = bd_tw_fwd<E>((low + (jl << S2)) << (LGN - (S2 + t + 1)));
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++)
+#pragma unroll
+        for (int t = 0; t < C::NS3; t++)
+#pragma unroll
+            for (int jl = 0; jl < (1 << t); jl++)
+                tw3[g][(1 << t) - 1 + jl] = bd_tw_fwd<E>((lane + 64 * g + (jl << S3)) << (LGN - (S3 + t + 1)));
+#pragma unroll
+    for (int t = 0; t < E; t++) twp[t] = bd_tw_cs<E>(lane + 64 * t);
 
-    float prev[E], prev_m = 0.f; // magnitudes of the previous frame: bins lane + 64 t, and bin M
+    // LDS addresses (in points): every access below is one of these plus a constant
+    constexpr int PADSH = C::PADSH;
+    v2f *t1 = tile + E * lane + ((E * lane) >> PADSH);                        // phase 1: point E * lane + q
+    const int base2 = (high << (S2 + C::NS2)) + low;
+    v2f *t2 = tile + base2 + (base2 >> PADSH);                                // phase 2: point base2 + i * E
+    v2f *t3 = tile + lane + (lane >> PADSH);                                  // phase 3: point lane + 64 t
+    v2f *t4 = tile + lane;                                                    // mirror exchange: Z[lane + 64 t]
+    const v2f *t5 = tile + M - lane;                                          //                  Z[M - lane - 64 t]
+
+    float prev[E], prev_m = 0.f; // doubled magnitudes of the previous frame: bins lane + 64 t, and bin M
 #pragma unroll
     for (int t = 0; t < E; t++) prev[t] = 0.f;
 
     // raw points (two i16 per dword) of the current frame
     unsigned raw[E];
     const uint64_t f_first = f0 > 0 ? f0 - 1 : 0; // one frame of warm-up gives the flux its predecessor
-    const unsigned *fp = reinterpret_cast<const unsigned *>(sp + f_first * (uint64_t)M);
+    const unsigned *fp = reinterpret_cast<const unsigned *>(sp + f_first * (uint64_t)M) + r6;
 #pragma unroll
-    for (int q = 0; q < E; q++) raw[q] = __builtin_nontemporal_load(fp + nq[q]);
+    for (int q = 0; q < E; q++) raw[q] = __builtin_nontemporal_load(fp + bd_rev_bits(q, LGE) * 64);
 
     for (uint64_t f = f_first; f < f_end; f++) {
-        float zr[E], zi[E];
+        v2f z[E];
 #pragma unroll
         for (int q = 0; q < E; q++) {
             const int d = (int)raw[q];
-            const float x0 = (float)(short)(d & 0xffff), x1 = (float)(short)(d >> 16);
-            zr[q] = a.window ? w0[q] * x0 : x0;
-            zi[q] = a.window ? w1[q] * x1 : x1;
+            const v2f x = v2f{(float)(short)(d & 0xffff), (float)(short)(d >> 16)};
+            z[q] = win_lds[q][lane] * x;   // (exact for the rectangular window: 1 * x)
         }
         // next frame: its first half is this frame's second half (odd slots -> even slots)
         if (f + 1 < f_end) {
-            const unsigned *np = reinterpret_cast<const unsigned *>(sp + (f + 1) * (uint64_t)M);
+            const unsigned *np = reinterpret_cast<const unsigned *>(sp + (f + 1) * (uint64_t)M) + r6;
 #pragma unroll
             for (int q = 0; q < E; q += 2) {
                 raw[q] = raw[q + 1];
-                raw[q + 1] = __builtin_nontemporal_load(np + nq[q + 1]);
+                raw[q + 1] = __builtin_nontemporal_load(np + bd_rev_bits(q + 1, LGE) * 64);
             }
         }
         // phase 1: stages 1 .. NS1 on points E*lane .. E*lane + E - 1 (bit-reversed order)
-        bd_fft_stages<E, C::NS1, 0, 1>(zr, zi, 0, tw_lds);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        bd_fft_phase1<E>(z);
+        bd_wave_lds_sync();
 #pragma unroll
-        for (int q = 0; q < E; q++) tile[bd_pad_d<E>(E * lane + q)] = make_float2(zr[q], zi[q]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < E; q++) t1[q] = z[q];
+        bd_wave_lds_sync();
         // phase 2: stages NS1+1 .. NS1+NS2 on points base + i * E
         {
-            constexpr int S0 = C::NS1, CNT = 1 << C::NS2;
-            const int low = lane & ((1 << S0) - 1);
-            const int base = ((lane >> S0) << (S0 + C::NS2)) + low;
-            float yr[CNT], yi[CNT];
+            v2f y[CNT2];
 #pragma unroll
-            for (int i = 0; i < CNT; i++) { const float2 v = tile[bd_pad_d<E>(base + (i << S0))]; yr[i] = v.x; yi[i] = v.y; }
-            bd_fft_stages<E, C::NS2, S0, 1>(yr, yi, low, tw_lds);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < CNT2; i++) y[i] = t2[i * E + ((i * E) >> PADSH)];
+            bd_fft_phase<C::NS2, 1>(y, tw2);
+            bd_wave_lds_sync();
 #pragma unroll
-            for (int i = 0; i < CNT; i++) tile[bd_pad_d<E>(base + (i << S0))] = make_float2(yr[i], yi[i]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < CNT2; i++) t2[i * E + ((i * E) >> PADSH)] = y[i];
+            bd_wave_lds_sync();
         }
         // phase 3: the last NS3 stages; afterwards slot t holds Z[lane + 64 t]
-        {
-            constexpr int S0 = C::NS1 + C::NS2, CNT = 1 << C::NS3, GROUPS = E / CNT;
 #pragma unroll
-            for (int t = 0; t < E; t++) { const float2 v = tile[bd_pad_d<E>(lane + 64 * t)]; zr[t] = v.x; zi[t] = v.y; }
-            // group g: points (lane + 64 g) + i * 2^S0  ->  slots g + GROUPS * i
+        for (int t = 0; t < E; t++) z[t] = t3[t * C::ROW3];
+        // group g: points (lane + 64 g) + i * 2^S3  ->  slots g + GROUPS * i
 #pragma unroll
-            for (int g = 0; g < GROUPS; g++)
-                bd_fft_stages<E, C::NS3, S0, GROUPS>(zr + g, zi + g, lane + 64 * g, tw_lds);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        for (int g = 0; g < GROUPS; g++) bd_fft_phase<C::NS3, GROUPS>(z + g, tw3[g]);
+        bd_wave_lds_sync();
 #pragma unroll
-            for (int t = 0; t < E; t++) tile[bd_pad_d<E>(lane + 64 * t)] = make_float2(zr[t], zi[t]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        // real-input post-processing and magnitudes
-        float flux_p = 0.f, band_p = 0.f;
-        float mag[E];
+        for (int t = 0; t < E; t++) t4[64 * t] = z[t];
+        if (lane == 0) tile[M] = z[0]; // Z[M] := Z[0], the partner of bin 0
+        bd_wave_lds_sync();
+        // real-input post-processing (spectrum carried at twice its value): squared magnitudes
+        float xs[E], xs_m, x_min;
 #pragma unroll
         for (int t = 0; t < E; t++) {
-            const int k = lane + 64 * t;
-            const float2 q = tile[bd_pad_d<E>((M - k) & (M - 1))];
-            const float2 w = tw_lds[bd_pad_t(k)];
-            const float er = 0.5f * (zr[t] + q.x), ei = 0.5f * (zi[t] - q.y);
-            const float dr = 0.5f * (zr[t] - q.x), di = 0.5f * (zi[t] + q.y);
-            const float cdr = w.x * dr, cdi = w.x * di;
-            const float pr = __builtin_fmaf(w.y, di, cdr), qi = __builtin_fmaf(-w.y, dr, cdi);
-            const float xr = er + qi, xi = ei - pr;
-            const float xi2 = xi * xi;
-            mag[t] = __builtin_sqrtf(__builtin_fmaf(xr, xr, xi2));
-            const float d = mag[t] - prev[t];
+            const v2f y = bd_post_bin(z[t], t5[-64 * t], twp[t]);
+            const float yi2 = y.y * y.y;
+            xs[t] = __builtin_fmaf(y.x, y.x, yi2);
+            x_min = t == 0 ? xs[0] : fminf(x_min, xs[t]);
+        }
+        {   // bin M pairs Z[0] with itself, twiddle (cos pi, sin pi) = (-1, 0)
+            const v2f z0 = tile[0];
+            const v2f y = bd_post_bin(z0, z0, bd_tw_cs<E>(M));
+            const float yi2 = y.y * y.y;
+            xs_m = __builtin_fmaf(y.x, y.x, yi2);
+            x_min = fminf(x_min, xs_m);
+        }
+        // magnitudes; a wavefront with a tiny or zero argument takes the library square root
+        if (__builtin_amdgcn_ballot_w64(x_min < 0x1p-96f) != 0) {
+#pragma unroll
+            for (int t = 0; t < E; t++) xs[t] = __builtin_sqrtf(xs[t]);
+            xs_m = __builtin_sqrtf(xs_m);
+        } else {
+#pragma unroll
+            for (int t = 0; t < E; t++) xs[t] = bd_sqrt_rn_normal(xs[t]);
+            xs_m = bd_sqrt_rn_normal(xs_m);
+        }
+        // lane l sums its bins l, l + 64, ... in ascending order (zero terms of the band sum skipped)
+        float flux_p = 0.f, band_p = (uint32_t)lane <= a.kmax ? xs[0] * xs[0] : 0.f;
+        if (__builtin_expect(a.kmax >= 64, 0)) {
+#pragma unroll
+            for (int t = 1; t < E; t++) band_p += (uint32_t)(lane + 64 * t) <= a.kmax ? xs[t] * xs[t] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < E; t++) {
+            const float d = xs[t] - prev[t];
             flux_p += d > 0.f ? d : 0.f;
-            band_p += (uint32_t)k <= a.kmax ? mag[t] * mag[t] : 0.f;
-            prev[t] = mag[t];
+            prev[t] = xs[t];
         }
-        {   // bin M pairs Z[0] with itself, twiddle (cos pi, sin pi)
-            const float2 z0 = tile[bd_pad_d<E>(0)];
-            const float2 w = tw_lds[bd_pad_t(M)];
-            const float er = 0.5f * (z0.x + z0.x), ei = 0.5f * (z0.y - z0.y);
-            const float dr = 0.5f * (z0.x - z0.x), di = 0.5f * (z0.y + z0.y);
-            const float cdr = w.x * dr, cdi = w.x * di;
-            const float pr = __builtin_fmaf(w.y, di, cdr), qi = __builtin_fmaf(-w.y, dr, cdi);
-            const float xr = er + qi, xi = ei - pr;
-            const float xi2 = xi * xi;
-            const float mm = __builtin_sqrtf(__builtin_fmaf(xr, xr, xi2));
-            if (lane == 0) {
-                const float d = mm - prev_m;
-                flux_p += d > 0.f ? d : 0.f;
-                band_p += (uint32_t)M <= a.kmax ? mm * mm : 0.f;
-            }
-            prev_m = mm;
+        if (lane == 0) {
+            const float d = xs_m - prev_m;
+            flux_p += d > 0.f ? d : 0.f;
+            band_p += (uint32_t)M <= a.kmax ? xs_m * xs_m : 0.f;
         }
-        const float flux = bd_xor_tree_sum(flux_p);
-        const float band = bd_xor_tree_sum(band_p);
-        if (f >= f0 && lane == 0) {
+        prev_m = xs_m;
+        const float flux = 0.5f * bd_butterfly_sum_lane63(flux_p);
+        const float band = 0.25f * bd_butterfly_sum_lane63(band_p);
+        if (f >= f0 && lane == 63) {
             out_lds[wave][0][f - f0] = flux;
             out_lds[wave][1][f - f0] = band;
         }
     }
     // results of the run, contiguous
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    bd_wave_lds_sync();
     const unsigned n_res = (unsigned)(f_end - f0);
     const uint64_t o0 = s * a.out_stride + f0;
     if (a.flux) {

@@ -16,19 +16,25 @@
  *        stage 2:  t = b for j = 0,  t = (b.im, -b.re) for j = 1
  *        stage >= 3:  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
  *        a' = a + t,  b' = a - t
+ *    (A butterfly whose twiddle is exactly (1, 0) or (0, -1) may equally be evaluated
+ *    with the shortcut of stage 1 / stage 2 or with the general formula: the two differ
+ *    in the sign of zeros only, which no output depends on.)
  * 4. Real-input post-processing, k = 0 .. M, with P = Z[k mod M], Q = Z[(M - k) mod M],
- *    (c, s) = BD_EXT_TW<N>[k]:
- *        er = 0.5 * (P.re + Q.re)      ei = 0.5 * (P.im - Q.im)
- *        dr = 0.5 * (P.re - Q.re)      di = 0.5 * (P.im + Q.im)
+ *    (c, s) = BD_EXT_TW<N>[k].  The halving of the textbook formula is deferred: the
+ *    spectrum is carried at twice its value (Y = 2 X) and the factor is applied once to
+ *    each sum.
+ *        er = P.re + Q.re              ei = P.im - Q.im
+ *        dr = P.re - Q.re              di = P.im + Q.im
  *        pr = fma(s, di, c * dr)       qi = fma(-s, dr, c * di)
- *        X.re = er + qi                X.im = ei - pr
- *        mag[k] = sqrt(fma(X.re, X.re, X.im * X.im))
+ *        Y.re = er + qi                Y.im = ei - pr
+ *        m2[k] = sqrt(fma(Y.re, Y.re, Y.im * Y.im))             (= 2 |X[k]|)
  * 5. Sums over bins (flux, band energy) are taken as 64 interleaved partial sums
  *    (partial l adds the terms of k = l, l + 64, ... in ascending order, the term of
  *    k = M last into partial 0) combined by the butterfly p[l] += p[l ^ o],
- *    o = 32, 16, 8, 4, 2, 1.
- *        flux[j] = sum_k max(0, mag_j[k] - mag_{j-1}[k])      (mag_{-1} = 0)
- *        band_energy[j] = sum_{k <= kmax} mag_j[k]^2            (terms fma-free: m * m)
+ *    o = 1, 2, 4, 8, 16, 32.
+ *        flux[j] = 0.5 * sum_k max(0, m2_j[k] - m2_{j-1}[k])     (m2_{-1} = 0)
+ *        band_energy[j] = 0.25 * sum_{k <= kmax} m2_j[k]^2        (terms fma-free: m * m)
+ *    and |X[k]| = 0.5 * m2[k] where a magnitude is reported.
  */
 #include "bd_oracle_ext.h"
 
@@ -69,7 +75,8 @@ static const float (*tw_table(uint32_t n))[2]
 
 static int log2u(uint32_t v) { int r = 0; while ((1u << r) < v) r++; return r; }
 
-int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
+/* m2[k] = 2 |X[k]| of one frame (items 1 - 4) */
+static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
 {
     if (n != 1024 && n != 2048) return -1;
     const float (*tw)[2] = tw_table(n);
@@ -111,8 +118,8 @@ int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *m
     for (uint32_t k = 0; k <= m; k++) {
         const uint32_t kp = k % m, kq = (m - k) % m;
         const float c = tw[k][0], s = tw[k][1];
-        const float er = 0.5f * (re[kp] + re[kq]), ei = 0.5f * (im[kp] - im[kq]);
-        const float dr = 0.5f * (re[kp] - re[kq]), di = 0.5f * (im[kp] + im[kq]);
+        const float er = re[kp] + re[kq], ei = im[kp] - im[kq];
+        const float dr = re[kp] - re[kq], di = im[kp] + im[kq];
         const float cdr = c * dr, cdi = c * di;
         const float pr = fmaf(s, di, cdr), qi = fmaf(-s, dr, cdi);
         const float xr = er + qi, xi = ei - pr;
@@ -120,6 +127,13 @@ int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *m
         mag[k] = sqrtf(fmaf(xr, xr, xi2));
     }
     free(re); free(im);
+    return 0;
+}
+
+int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
+{
+    if (rfft_mag2(frame, n, window, mag) != 0) return -1;
+    for (uint32_t k = 0; k <= n / 2; k++) mag[k] = 0.5f * mag[k];
     return 0;
 }
 
@@ -150,7 +164,7 @@ static float lane_sum(const float *term, uint32_t m /* terms for k = 0 .. m */)
         p[l] = s;
     }
     p[0] += term[m];
-    for (int o = 32; o >= 1; o >>= 1) {
+    for (int o = 1; o <= 32; o <<= 1) {
         float q[64];
         for (int l = 0; l < 64; l++) q[l] = p[l] + p[l ^ o];
         memcpy(p, q, sizeof(p));
@@ -171,14 +185,14 @@ int bdo_onset_stft(const int16_t *samples, size_t n_samples, uint32_t sampling_r
     uint32_t kmax = 0;
     for (uint32_t k = 0; k <= m; k++) { if ((float)k * res <= p->band_max_hz) kmax = k; else break; }
     for (size_t j = 0; j < frames; j++) {
-        bdo_ext_rfft_mag(samples + j * p->hop, n, p->window, cur);
+        rfft_mag2(samples + j * p->hop, n, p->window, cur);
         if (flux) {
             for (uint32_t k = 0; k <= m; k++) { const float d = cur[k] - prev[k]; term[k] = d > 0.0f ? d : 0.0f; }
-            flux[j] = lane_sum(term, m);
+            flux[j] = 0.5f * lane_sum(term, m);
         }
         if (band_energy) {
             for (uint32_t k = 0; k <= m; k++) term[k] = k <= kmax ? cur[k] * cur[k] : 0.0f;
-            band_energy[j] = lane_sum(term, m);
+            band_energy[j] = 0.25f * lane_sum(term, m);
         }
         float *t = prev; prev = cur; cur = t;
     }
