@@ -52,15 +52,19 @@ template <int E> struct bd_fft_cfg {
     static constexpr int NS1 = LGE;            // stages per phase
     static constexpr int NS2 = (E == 16) ? 4 : 3;
     static constexpr int NS3 = (LGE + 6) - NS1 - NS2;
-    // Complex tile of one wavefront.  Point p of the transform lives at p + (p >> PADSH):
-    // with one pad slot per 32 points (N = 2048) the three access patterns -- 16
-    // consecutive points per lane, points 16 apart per lane, points 64 apart per lane --
-    // are all free of bank conflicts (the second needs the lane order of phase 2 below);
-    // N = 1024 pads every 8 points, which leaves a few two-way conflicts in phase 3.
-    // The exchange with the mirror bin M - k uses the plain index and one more slot (Z[M] := Z[0]).
-    static constexpr int PADSH = (E == 16) ? 5 : 3;
-    static constexpr int DATA_LEN = M + (M >> PADSH) + 1;
-    static constexpr int ROW3 = 64 + (64 >> PADSH);  // padded distance of points 64 apart
+    // Complex tile of one wavefront.  Point p of the transform lives at p + (p >> PAD1) in
+    // the exchange between phases 1 and 2 and at p + (p >> PAD2) in the exchange between
+    // phases 2 and 3.  ds_write_b64 is banked on 32 dwords over groups of 16 lanes,
+    // ds_read_b64 on 64 dwords over groups of 32 lanes: for N = 2048 one pad slot per 16
+    // points makes the first exchange conflict-free (lanes 16 points apart write, lanes read
+    // points 16 apart), one per 32 points the second (lanes write points 16 apart, 64
+    // consecutive lanes read).  N = 1024 pads every 8 points in both (a few two-way
+    // conflicts remain in phase 3).  The exchange with the mirror bin M - k uses the plain
+    // index and one more slot (Z[M] := Z[0]).
+    static constexpr int PAD1 = (E == 16) ? 4 : 3;
+    static constexpr int PAD2 = (E == 16) ? 5 : 3;
+    static constexpr int DATA_LEN = M + (M >> 3) + 1;
+    static constexpr int ROW3 = 64 + (64 >> PAD2);  // padded distance of points 64 apart
 };
 
 // (cos, -sin)(2 pi idx / N): the butterfly twiddle
@@ -90,9 +94,10 @@ __device__ __forceinline__ int bd_rev_bits(int v, int bits)
 // t = w * b with w = (wr, wi):  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
 __device__ __forceinline__ v2f bd_cmul(v2f b, v2f w)
 {
-    v2f p, t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(b), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(b), "v"(w), "v"(p));
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(t) : "v"(b), "v"(w));
     return t;
 }
 __device__ __forceinline__ void bd_bfly(v2f &a, v2f &b, v2f t)
@@ -105,21 +110,22 @@ __device__ __forceinline__ void bd_bfly(v2f &a, v2f &b, v2f t)
 __device__ __forceinline__ void bd_bfly_rot(v2f &a, v2f &b)
 {
     v2f ra, rb;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(ra) : "v"(a), "v"(b));
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(rb) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(ra), "=&v"(rb) : "v"(a), "v"(b));
     a = ra; b = rb;
 }
 // Real-input post-processing of one bin (spectrum at twice its value):
 // z = Z[k], q = Z[M - k], cs = (cos, sin)(2 pi k / N); returns (Y.re, Y.im)
 __device__ __forceinline__ v2f bd_post_bin(v2f z, v2f q, v2f cs)
 {
-    v2f e, d, u, pq, y;
-    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(e) : "v"(z), "v"(q));                 // (zr + qr, zi - qi)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(z), "v"(q));                 // (zr - qr, zi + qi)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(u) : "v"(cs), "v"(d));             // (c dr, c di)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
-        : "=v"(pq) : "v"(cs), "v"(d), "v"(u));                                              // (fma(s,di,c dr), fma(-s,dr,c di))
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(y) : "v"(e), "v"(pq)); // (er + qi, ei - pr)
+    v2f e, d, y;
+    asm("v_pk_add_f32 %0, %3, %4 neg_hi:[0,1]\n\t"                                     // e = (zr + qr, zi - qi)
+        "v_pk_add_f32 %1, %3, %4 neg_lo:[0,1]\n\t"                                     // d = (zr - qr, zi + qi)
+        "v_pk_mul_f32 %2, %5, %1 op_sel_hi:[0,1]\n\t"                                  // (c dr, c di)
+        "v_pk_fma_f32 %2, %5, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t" // (fma(s,di,c dr), fma(-s,dr,c di))
+        "v_pk_add_f32 %2, %0, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"             // (er + qi, ei - pr)
+        : "=&v"(e), "=&v"(d), "=&v"(y) : "v"(z), "v"(q), "v"(cs));
     return y;
 }
 
@@ -150,14 +156,20 @@ __device__ __forceinline__ void bd_fft_phase1(v2f *z)
 template <int NS, int STRIDE>
 __device__ __forceinline__ void bd_fft_phase(v2f *z, const v2f *tw)
 {
+    constexpr int H = 1 << (NS - 1);
 #pragma unroll
     for (int t = 0; t < NS; t++) {
+        v2f tv[H];
+        // pair n: a = ((n >> t) << (t + 1)) + (n & ((1 << t) - 1)), b = a + (1 << t), twiddle jl = n & ((1 << t) - 1)
 #pragma unroll
-        for (int i = 0; i < (1 << NS); i++) {
-            if (i & (1 << t)) continue;
-            const int ia = i * STRIDE, ib = (i + (1 << t)) * STRIDE;
-            const v2f tv = bd_cmul(z[ib], tw[(1 << t) - 1 + (i & ((1 << t) - 1))]);
-            bd_bfly(z[ia], z[ib], tv);
+        for (int n = 0; n < H; n++) {
+            const int jl = n & ((1 << t) - 1), ib = (((n >> t) << (t + 1)) + jl + (1 << t)) * STRIDE;
+            tv[n] = bd_cmul(z[ib], tw[(1 << t) - 1 + jl]);
+        }
+#pragma unroll
+        for (int n = 0; n < H; n++) {
+            const int jl = n & ((1 << t) - 1), ia = (((n >> t) << (t + 1)) + jl) * STRIDE, ib = ia + (1 << t) * STRIDE;
+            bd_bfly(z[ia], z[ib], tv[n]);
         }
     }
 }
@@ -171,8 +183,7 @@ __device__ __forceinline__ float bd_sqrt_rn_normal(float x)
     const int si = __builtin_bit_cast(int, s);
     const float sd = __builtin_bit_cast(float, si - 1), su = __builtin_bit_cast(float, si + 1);
     float vd, vu; // x - sd * s, x - su * s (assembly keeps the negation a source modifier of a scalar fma)
-    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vd) : "v"(sd), "v"(s), "v"(x));
-    asm("v_fma_f32 %0, -%1, %2, %3" : "=v"(vu) : "v"(su), "v"(s), "v"(x));
+    asm("v_fma_f32 %0, -%2, %4, %5\n\tv_fma_f32 %1, -%3, %4, %5" : "=&v"(vd), "=&v"(vu) : "v"(sd), "v"(su), "v"(s), "v"(x));
     return __builtin_bit_cast(float, si - 1 + (vd > 0.f ? 1 : 0) + (vu > 0.f ? 1 : 0));
 }
 
@@ -190,6 +201,15 @@ __device__ __forceinline__ float bd_butterfly_sum_lane63(float p)
     p = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x142, 0xa, 0xf, true)); // row_bcast:15 -> rows 1, 3
     p = p + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x143, 0xc, 0xf, true)); // row_bcast:31 -> rows 2, 3
     return p;
+}
+
+// One ds_read_b64 per point.  The volatile access keeps the compiler from pairing
+// two of them into a ds_read2_b64, which moves the same bytes in twice the LDS
+// cycles and is banked on 32 instead of 64 dwords.
+__device__ __forceinline__ v2f bd_lds_read(const v2f *p)
+{
+    typedef const volatile __attribute__((address_space(3))) v2f *lds_ptr;
+    return *(lds_ptr)p;
 }
 
 __device__ __forceinline__ void bd_wave_lds_sync()
@@ -230,8 +250,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
     // per-lane twiddles of the second and third phase and of the post-processing
     constexpr int S2 = C::NS1, S3 = C::NS1 + C::NS2, CNT2 = 1 << C::NS2, CNT3 = 1 << C::NS3, GROUPS = E / CNT3;
     const int low = lane & ((1 << S2) - 1);
-    // group of phase 2: lanes 16 apart take groups two apart (N = 2048), see bd_fft_cfg
-    const int high = E == 16 ? ((lane >> 4) & 1) * 2 + (lane >> 5) : lane >> S2;
+    const int high = lane >> S2;
     v2f tw2[CNT2 - 1], tw3[GROUPS][CNT3 - 1], twp[E];
 #pragma unroll
     for (int t = 0; t < C::NS2; t++)
@@ -249,11 +268,12 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
     for (int t = 0; t < E; t++) twp[t] = bd_tw_cs<E>(lane + 64 * t);
 
     // LDS addresses (in points): every access below is one of these plus a constant
-    constexpr int PADSH = C::PADSH;
-    v2f *t1 = tile + E * lane + ((E * lane) >> PADSH);                        // phase 1: point E * lane + q
-    const int base2 = (high << (S2 + C::NS2)) + low;
-    v2f *t2 = tile + base2 + (base2 >> PADSH);                                // phase 2: point base2 + i * E
-    v2f *t3 = tile + lane + (lane >> PADSH);                                  // phase 3: point lane + 64 t
+    constexpr int PAD1 = C::PAD1, PAD2 = C::PAD2;
+    v2f *t1 = tile + E * lane + ((E * lane) >> PAD1);                         // phase 1 out: point E * lane + q
+    const int base2 = (high << (S2 + C::NS2)) + low;                          // phase 2: point base2 + i * E
+    const v2f *t2r = tile + base2 + (base2 >> PAD1);
+    v2f *t2w = tile + base2 + (base2 >> PAD2);
+    const v2f *t3 = tile + lane + (lane >> PAD2);                             // phase 3 in: point lane + 64 t
     v2f *t4 = tile + lane;                                                    // mirror exchange: Z[lane + 64 t]
     const v2f *t5 = tile + M - lane;                                          //                  Z[M - lane - 64 t]
 
@@ -274,7 +294,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         for (int q = 0; q < E; q++) {
             const int d = (int)raw[q];
             const v2f x = v2f{(float)(short)(d & 0xffff), (float)(short)(d >> 16)};
-            z[q] = win_lds[q][lane] * x;   // (exact for the rectangular window: 1 * x)
+            z[q] = bd_lds_read(&win_lds[q][lane]) * x;   // (exact for the rectangular window: 1 * x)
         }
         // next frame: its first half is this frame's second half (odd slots -> even slots)
         if (f + 1 < f_end) {
@@ -295,16 +315,16 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         {
             v2f y[CNT2];
 #pragma unroll
-            for (int i = 0; i < CNT2; i++) y[i] = t2[i * E + ((i * E) >> PADSH)];
+            for (int i = 0; i < CNT2; i++) y[i] = bd_lds_read(t2r + i * E + ((i * E) >> PAD1));
             bd_fft_phase<C::NS2, 1>(y, tw2);
             bd_wave_lds_sync();
 #pragma unroll
-            for (int i = 0; i < CNT2; i++) t2[i * E + ((i * E) >> PADSH)] = y[i];
+            for (int i = 0; i < CNT2; i++) t2w[i * E + ((i * E) >> PAD2)] = y[i];
             bd_wave_lds_sync();
         }
         // phase 3: the last NS3 stages; afterwards slot t holds Z[lane + 64 t]
 #pragma unroll
-        for (int t = 0; t < E; t++) z[t] = t3[t * C::ROW3];
+        for (int t = 0; t < E; t++) z[t] = bd_lds_read(t3 + t * C::ROW3);
         // group g: points (lane + 64 g) + i * 2^S3  ->  slots g + GROUPS * i
 #pragma unroll
         for (int g = 0; g < GROUPS; g++) bd_fft_phase<C::NS3, GROUPS>(z + g, tw3[g]);
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         float xs[E], xs_m, x_min;
 #pragma unroll
         for (int t = 0; t < E; t++) {
-            const v2f y = bd_post_bin(z[t], t5[-64 * t], twp[t]);
+            const v2f y = bd_post_bin(z[t], bd_lds_read(t5 - 64 * t), twp[t]);
             const float yi2 = y.y * y.y;
             xs[t] = __builtin_fmaf(y.x, y.x, yi2);
             x_min = t == 0 ? xs[0] : fminf(x_min, xs[t]);
