@@ -9,6 +9,8 @@ fails loudly when the library or a GPU is missing.
 """
 from .api import (  # noqa: F401
     BeatInfo,
+    BiquadDesign,
+    BiquadParams,
     BeatDetectorError,
     FMT_F32,
     FMT_I16,
@@ -36,3 +38,4 @@ from .api import (  # noqa: F401
     u16_data_to_i16,
 )
 from .onset import OnsetResult, onset_batch, onset_frames, onset_pick, onset_stft  # noqa: F401,E402
+from .biquad import biquad_beats, biquad_design, biquad_envelope  # noqa: F401,E402

@@ -102,6 +102,30 @@ class OnsetParams(C.Structure):
         return p
 
 
+class BiquadDesign(C.Structure):
+    """bd_biquad_design of include/beat_detector_hip.h (extension analysis)."""
+
+    _fields_ = [("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("na1", C.c_float), ("na2", C.c_float),
+                ("pw", (C.c_float * 4) * 6), ("q", (C.c_float * 4) * 64)]
+
+
+class BiquadParams(C.Structure):
+    """bd_biquad_params of include/beat_detector_hip.h (extension analysis)."""
+
+    _fields_ = [("cutoff_hz", C.c_uint32), ("q_factor", C.c_float), ("window_len", C.c_uint32),
+                ("ratio", C.c_float), ("min_amplitude", C.c_uint32)]
+
+    @classmethod
+    def default(cls, **overrides) -> "BiquadParams":
+        p = cls()
+        lib().bd_biquad_default_params(C.byref(p))
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+
 class InputSource(C.Structure):
     """bd_input_source: the stand-in for a cpal input device."""
 
@@ -173,6 +197,10 @@ def lib() -> C.CDLL:
         "bd_onset_stft": (i32, [u32, op, vp, u64, u64, u64, vp, vp, u64, vp]),
         "bd_onset_pick": (i32, [u32, op, vp, u64, u64, u64, vp, vp, vp, vp, u32, vp]),
         "bd_onset_batch": (i32, [u32, op, vp, u64, u64, u64, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_biquad_default_params": (None, [C.POINTER(BiquadParams)]),
+        "bd_biquad_design_lowpass": (i32, [u32, u32, f32, C.POINTER(BiquadDesign)]),
+        "bd_biquad_envelope": (i32, [u32, C.POINTER(BiquadParams), C.POINTER(BiquadDesign), vp, u64, u64, u64, vp, vp,
+                                     u64, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -190,7 +218,7 @@ EXPORTED_SYMBOLS = (
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
-    "bd_onset_stft bd_onset_pick bd_onset_batch"
+    "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope"
 ).split()
 
 

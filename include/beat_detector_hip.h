@@ -285,6 +285,37 @@ int bd_onset_batch(uint32_t sampling_rate, const bd_onset_params *p, const int16
                    uint32_t *onset_count, uint32_t *onset_frame, uint32_t *onset_ms,
                    uint32_t max_onsets, void *hip_stream);
 
+/* ---- extension analysis: carried-state biquad envelope ------------------ */
+/* NO COUNTERPART IN THE REFERENCE: its low-pass is first order and restarts in
+ * every window (src/strategies/lpf.rs:66-71).  Here a second-order low-pass runs
+ * through the whole stream (state carried across windows), evaluated in chunks
+ * of 64 samples joined by a scan; per decision window the envelope max |y| is
+ * compared with trunc(ratio * max |x|), gated by min_amplitude as in
+ * src/lib.rs:133-136.  Results are defined by the CPU definition the tests hold
+ * (same f32 operation order: bit-identical), not by the reference. */
+typedef struct bd_biquad_design {
+    float b0, b1, b2, na1, na2;   /* y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])); u = FIR part */
+    float pw[6][4];               /* P^(2^k), k = 0..5; P = state transition over 64 samples (row-major 2x2) */
+    float q[64][4];               /* P^(l+1), l = 0..63 */
+} bd_biquad_design;
+typedef struct bd_biquad_params {
+    uint32_t cutoff_hz;      /* 120 */
+    float    q_factor;       /* 0.70710678 (Butterworth) */
+    uint32_t window_len;     /* decision window: power of two, 64 .. 4096 (1024) */
+    float    ratio;          /* 0.77, src/strategies/lpf.rs:75 */
+    uint32_t min_amplitude;  /* 9830, src/lib.rs:134 */
+} bd_biquad_params;
+void bd_biquad_default_params(bd_biquad_params *p);
+/* RBJ low-pass designed in float64 and rounded once (host only, no GPU needed). */
+int bd_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_hz, float q_factor, bd_biquad_design *d);
+/* values[s * out_stride + w] = max |y| over window w (may be NULL), flags[...] = decision.
+ * params NULL = defaults; design NULL = designed from params and sampling_rate.
+ * Device pointers, enqueue only; rows of `samples` must start on 16-byte boundaries.
+ * One wavefront per stream: the launch fills the GPU from about 2,000 streams up. */
+int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params *params, const bd_biquad_design *design,
+                       const int16_t *samples, uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,
+                       float *values, uint8_t *flags, uint64_t out_stride, void *hip_stream);
+
 /* ---- instrumentation --------------------------------------------------- */
 /* Name and grid of the dominant kernel of the last bd_analyze_batch call on
  * this thread (for profilers). */

@@ -235,3 +235,159 @@ size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate
     }
     return count;
 }
+
+/* ======================================================================
+ * Carried-state biquad envelope.  Arithmetic specification (all f32, fma
+ * exactly where written):
+ *
+ * 1. Design: RBJ low-pass in float64 (w0 = 2 pi fc / fs, alpha = sin w0 / (2 Q),
+ *    b0 = b2 = (1 - cos w0) / 2, b1 = 1 - cos w0, a0 = 1 + alpha, a1 = -2 cos w0,
+ *    a2 = 1 - alpha), normalised by a0 and rounded to f32: b0, b1, b2, na1 = -a1/a0,
+ *    na2 = -a2/a0.  A = [[na1, na2], [1, 0]] (from the rounded coefficients, as
+ *    float64), P = A^64; pw[k] = P^(2^k), q[l] = P^(l+1), computed in float64 by
+ *    repeated multiplication and rounded to f32.
+ * 2. u[n] = fma(b2, x[n-2], fma(b1, x[n-1], b0 * x[n])), x[-1] = x[-2] = 0.
+ * 3. The stream is cut into chunks of 64 samples; 64 consecutive chunks form a
+ *    step (4096 samples).  A trailing partial step is evaluated with the missing
+ *    chunks' input taken as zero (their results are not reported).
+ *    Zero-state response of chunk l of a step: z[-1] = z[-2] = 0,
+ *    z[n] = fma(na2, z[n-2], fma(na1, z[n-1], u[n])); r_l = (z[63], z[62]).
+ * 4. Inclusive scan over the 64 chunks of a step (Hillis-Steele, k = 0..5):
+ *    v_l <- M_k v_{l - 2^k} + v_l for l >= 2^k, with M_k = pw[k] and
+ *    (M v + w).a = fma(M01, v.b, fma(M00, v.a, w.a)), .b = fma(M11, v.b, fma(M10, v.a, w.b)).
+ * 5. State at the end of chunk l: e_l = q[l] s_in + v_l (same fma pattern), where
+ *    s_in is the state at the start of the step (zero for the first step, e_63 of
+ *    the previous step otherwise).  Chunk l starts from s_l = e_{l-1} (s_0 = s_in).
+ * 6. Output of chunk l: y[-1] = s_l.a, y[-2] = s_l.b,
+ *    y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])).
+ * 7. Per complete window: m = max |x| with -32768 counted as 32767; value = max |y|;
+ *    thr = (int)(ratio * (float)m) (truncation); flag = m >= min_amplitude && value >= (float)thr.
+ * ====================================================================== */
+void bdo_biquad_default_params(bdo_biquad_params *p)
+{
+    p->cutoff_hz = 120; p->q_factor = 0.70710678f; p->window_len = 1024; p->ratio = 0.77f; p->min_amplitude = 9830;
+}
+
+static void mat2_mul(const double a[4], const double b[4], double c[4])
+{
+    const double r0 = a[0] * b[0] + a[1] * b[2], r1 = a[0] * b[1] + a[1] * b[3];
+    const double r2 = a[2] * b[0] + a[3] * b[2], r3 = a[2] * b[1] + a[3] * b[3];
+    c[0] = r0; c[1] = r1; c[2] = r2; c[3] = r3;
+}
+
+int bdo_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_hz, float q_factor, bdo_biquad_design *d)
+{
+    if (!d || sampling_rate == 0 || cutoff_hz == 0 || 2.0 * cutoff_hz >= (double)sampling_rate || !(q_factor > 0.0f)) return -1;
+    const double pi = 3.14159265358979323846;
+    const double w0 = 2.0 * pi * (double)cutoff_hz / (double)sampling_rate;
+    const double cw = cos(w0), sw = sin(w0), alpha = sw / (2.0 * (double)q_factor);
+    const double a0 = 1.0 + alpha;
+    d->b0 = (float)(((1.0 - cw) / 2.0) / a0);
+    d->b1 = (float)((1.0 - cw) / a0);
+    d->b2 = d->b0;
+    d->na1 = (float)((2.0 * cw) / a0);
+    d->na2 = (float)(-(1.0 - alpha) / a0);
+    const double a[4] = {(double)d->na1, (double)d->na2, 1.0, 0.0};
+    double p[4] = {1.0, 0.0, 0.0, 1.0};
+    for (int i = 0; i < BDO_BQ_CHUNK; i++) mat2_mul(a, p, p);           /* P = A^64 */
+    double m[4] = {p[0], p[1], p[2], p[3]};
+    for (int k = 0; k < 6; k++) {
+        for (int j = 0; j < 4; j++) d->pw[k][j] = (float)m[j];
+        mat2_mul(m, m, m);                                              /* P^(2^k) */
+    }
+    double ql[4] = {p[0], p[1], p[2], p[3]};
+    for (int l = 0; l < 64; l++) {
+        for (int j = 0; j < 4; j++) d->q[l][j] = (float)ql[j];
+        mat2_mul(p, ql, ql);                                            /* P^(l+1) */
+    }
+    return 0;
+}
+
+static inline void affine2(const float m[4], float va, float vb, float wa, float wb, float *oa, float *ob)
+{
+    *oa = fmaf(m[1], vb, fmaf(m[0], va, wa));
+    *ob = fmaf(m[3], vb, fmaf(m[2], va, wb));
+}
+
+int bdo_biquad_envelope(const int16_t *samples, size_t n_samples, const bdo_biquad_design *d,
+                        const bdo_biquad_params *p, float *values, uint8_t *flags, float *y_out)
+{
+    const uint32_t w = p->window_len;
+    if (w < 64 || w > 4096 || (w & (w - 1))) return -1;
+    const size_t n_win = n_samples / w, n_used = n_win * w;
+    const size_t step = 64 * BDO_BQ_CHUNK, n_steps = (n_used + step - 1) / step;
+    float *u = (float *)malloc(step * sizeof(float)), *y = (float *)malloc(step * sizeof(float));
+    float sa = 0.0f, sb = 0.0f;   /* s_in */
+    float wmax_y = 0.0f; int wmax_x = 0;
+    for (size_t st = 0; st < n_steps; st++) {
+        const size_t base = st * step;
+        /* item 2 (samples beyond the analysed range count as zero) */
+        for (size_t i = 0; i < step; i++) {
+            const size_t n = base + i;
+            const float x0 = n < n_used ? (float)samples[n] : 0.0f;
+            const float x1 = (n >= 1 && n - 1 < n_used) ? (float)samples[n - 1] : 0.0f;
+            const float x2 = (n >= 2 && n - 2 < n_used) ? (float)samples[n - 2] : 0.0f;
+            u[i] = fmaf(d->b2, x2, fmaf(d->b1, x1, d->b0 * x0));
+        }
+        float va[64], vb[64];
+        for (int l = 0; l < 64; l++) {        /* item 3 */
+            float z1 = 0.0f, z2 = 0.0f;
+            for (int i = 0; i < BDO_BQ_CHUNK; i++) {
+                const float z = fmaf(d->na2, z2, fmaf(d->na1, z1, u[l * BDO_BQ_CHUNK + i]));
+                z2 = z1; z1 = z;
+            }
+            va[l] = z1; vb[l] = z2;
+        }
+        for (int k = 0; k < 6; k++) {          /* item 4 */
+            float na[64], nb[64];
+            for (int l = 0; l < 64; l++) {
+                if (l >= (1 << k)) affine2(d->pw[k], va[l - (1 << k)], vb[l - (1 << k)], va[l], vb[l], &na[l], &nb[l]);
+                else { na[l] = va[l]; nb[l] = vb[l]; }
+            }
+            memcpy(va, na, sizeof(va)); memcpy(vb, nb, sizeof(vb));
+        }
+        float ea[64], eb[64];
+        for (int l = 0; l < 64; l++) affine2(d->q[l], sa, sb, va[l], vb[l], &ea[l], &eb[l]);   /* item 5 */
+        for (int l = 0; l < 64; l++) {        /* item 6 */
+            float y1 = l ? ea[l - 1] : sa, y2 = l ? eb[l - 1] : sb;
+            for (int i = 0; i < BDO_BQ_CHUNK; i++) {
+                const float v = fmaf(d->na2, y2, fmaf(d->na1, y1, u[l * BDO_BQ_CHUNK + i]));
+                y[l * BDO_BQ_CHUNK + i] = v;
+                y2 = y1; y1 = v;
+            }
+        }
+        sa = ea[63]; sb = eb[63];
+        for (size_t i = 0; i < step && base + i < n_used; i++) {   /* item 7 */
+            const size_t n = base + i;
+            if (y_out) y_out[n] = y[i];
+            int ax = samples[n] == INT16_MIN ? 32767 : (samples[n] < 0 ? -samples[n] : samples[n]);
+            if (ax > wmax_x) wmax_x = ax;
+            const float ay = fabsf(y[i]);
+            if (ay > wmax_y) wmax_y = ay;
+            if ((n + 1) % w == 0) {
+                const size_t wi = n / w;
+                const int thr = (int)(p->ratio * (float)wmax_x);
+                if (values) values[wi] = wmax_y;
+                if (flags) flags[wi] = (uint8_t)((uint32_t)wmax_x >= p->min_amplitude && wmax_y >= (float)thr);
+                wmax_x = 0; wmax_y = 0.0f;
+            }
+        }
+    }
+    free(u); free(y);
+    return 0;
+}
+
+void bdo_biquad_filter_f64(const int16_t *samples, size_t n_samples, uint32_t sampling_rate, uint32_t cutoff_hz,
+                           double q_factor, double *y)
+{
+    const double pi = 3.14159265358979323846;
+    const double w0 = 2.0 * pi * (double)cutoff_hz / (double)sampling_rate;
+    const double cw = cos(w0), alpha = sin(w0) / (2.0 * q_factor), a0 = 1.0 + alpha;
+    const double b0 = ((1.0 - cw) / 2.0) / a0, b1 = (1.0 - cw) / a0, a1 = (-2.0 * cw) / a0, a2 = (1.0 - alpha) / a0;
+    double x1 = 0, x2 = 0, y1 = 0, y2 = 0;
+    for (size_t n = 0; n < n_samples; n++) {
+        const double x0 = samples[n];
+        const double v = b0 * x0 + b1 * x1 + b0 * x2 - a1 * y1 - a2 * y2;
+        y[n] = v; x2 = x1; x1 = x0; y2 = y1; y1 = v;
+    }
+}

@@ -56,6 +56,38 @@ size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate
                       const bdo_onset_params *p, uint8_t *candidates /*[n_frames] or NULL*/,
                       uint32_t *onset_frame, uint32_t *onset_ms, size_t max_onsets);
 
+/* ---- carried-state biquad envelope (extension, no reference counterpart) ----
+ * The reference's low-pass is first order and restarts in every window
+ * (src/strategies/lpf.rs:66-71).  This is the north-star variant: a second-order
+ * low-pass whose state is carried through the whole stream, evaluated in chunks of
+ * 64 samples so that the chunk-to-chunk recurrence is a scan.  See the .c file for
+ * the arithmetic specification. */
+#define BDO_BQ_CHUNK 64
+typedef struct bdo_biquad_design {
+    float b0, b1, b2, na1, na2;   /* y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])), u = FIR part */
+    float pw[6][4];               /* P^(2^k), k = 0..5, P = state transition over one chunk; row-major 2x2 */
+    float q[64][4];               /* P^(l+1), l = 0..63 */
+} bdo_biquad_design;
+
+typedef struct bdo_biquad_params {
+    uint32_t cutoff_hz;      /* 120 */
+    float    q_factor;       /* 0.70710678 */
+    uint32_t window_len;     /* decision window, power of two, 64 .. 4096 */
+    float    ratio;          /* 0.77: threshold = trunc(ratio * max|x|) */
+    uint32_t min_amplitude;  /* 9830 */
+} bdo_biquad_params;
+
+void bdo_biquad_default_params(bdo_biquad_params *p);
+/* RBJ low-pass, float64 design rounded once to f32; returns 0, or -1 for unusable parameters */
+int  bdo_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_hz, float q_factor, bdo_biquad_design *d);
+/* Per complete window of one stream: value = max |y| over the window (f32), flag = gate && value >= threshold.
+ * y_out (n_samples floats, may be NULL) receives the filtered signal of the complete chunks. */
+int  bdo_biquad_envelope(const int16_t *samples, size_t n_samples, const bdo_biquad_design *d,
+                         const bdo_biquad_params *p, float *values, uint8_t *flags, float *y_out);
+/* the same filter evaluated sample by sample in float64 (accuracy reference) */
+void bdo_biquad_filter_f64(const int16_t *samples, size_t n_samples, uint32_t sampling_rate, uint32_t cutoff_hz,
+                           double q_factor, double *y);
+
 #ifdef __cplusplus
 }
 #endif

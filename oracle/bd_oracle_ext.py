@@ -26,6 +26,16 @@ class OnsetParams(C.Structure):
     ]
 
 
+class BiquadDesign(C.Structure):
+    _fields_ = [("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("na1", C.c_float), ("na2", C.c_float),
+                ("pw", (C.c_float * 4) * 6), ("q", (C.c_float * 4) * 64)]
+
+
+class BiquadParams(C.Structure):
+    _fields_ = [("cutoff_hz", C.c_uint32), ("q_factor", C.c_float), ("window_len", C.c_uint32),
+                ("ratio", C.c_float), ("min_amplitude", C.c_uint32)]
+
+
 _ready = False
 
 
@@ -46,6 +56,12 @@ def lib() -> C.CDLL:
         L.bdo_onset_stft.argtypes = [vp, sz, u32, pp, vp, vp]
         L.bdo_onset_pick.argtypes = [vp, sz, u32, pp, vp, vp, vp, sz]
         L.bdo_onset_pick.restype = sz
+        L.bdo_biquad_default_params.argtypes = [C.POINTER(BiquadParams)]
+        L.bdo_biquad_default_params.restype = None
+        L.bdo_biquad_design_lowpass.argtypes = [u32, u32, C.c_float, C.POINTER(BiquadDesign)]
+        L.bdo_biquad_envelope.argtypes = [vp, sz, C.POINTER(BiquadDesign), C.POINTER(BiquadParams), vp, vp, vp]
+        L.bdo_biquad_filter_f64.argtypes = [vp, sz, u32, u32, C.c_double, vp]
+        L.bdo_biquad_filter_f64.restype = None
         _ready = True
     return L
 
@@ -112,3 +128,44 @@ def onset_pick(flux, sampling_rate: int, params: OnsetParams | None = None):
     ms = np.zeros(max(n, 1), dtype=np.uint32)
     cnt = lib().bdo_onset_pick(_vp(f), n, sampling_rate, C.byref(p), _vp(cand), _vp(frame), _vp(ms), n)
     return cand, frame[:cnt].copy(), ms[:cnt].copy()
+
+
+def biquad_params(**overrides) -> BiquadParams:
+    p = BiquadParams()
+    lib().bdo_biquad_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def biquad_design(sampling_rate: int, cutoff_hz: int = 120, q_factor: float = 0.70710678) -> BiquadDesign:
+    d = BiquadDesign()
+    if lib().bdo_biquad_design_lowpass(sampling_rate, cutoff_hz, q_factor, C.byref(d)) != 0:
+        raise ValueError("unusable biquad parameters")
+    return d
+
+
+def biquad_envelope(samples, sampling_rate: int, params: BiquadParams | None = None, design: BiquadDesign | None = None,
+                    want_y: bool = False):
+    """(values f32[n_windows], flags u8[n_windows][, y f32[n_windows * window_len]]) of one stream."""
+    p = params if params is not None else biquad_params()
+    d = design if design is not None else biquad_design(sampling_rate, p.cutoff_hz, p.q_factor)
+    x = np.ascontiguousarray(samples, dtype=np.int16)
+    nw = x.size // p.window_len
+    values = np.zeros(nw, dtype=np.float32)
+    flags = np.zeros(nw, dtype=np.uint8)
+    y = np.zeros(x.size, dtype=np.float32) if want_y else None
+    rc = lib().bdo_biquad_envelope(_vp(x), x.size, C.byref(d), C.byref(p), _vp(values), _vp(flags),
+                                   _vp(y) if want_y else None)
+    if rc != 0:
+        raise ValueError("window_len must be a power of two between 64 and 4096")
+    return (values, flags, y[:nw * p.window_len]) if want_y else (values, flags)
+
+
+def biquad_filter_f64(samples, sampling_rate: int, cutoff_hz: int = 120, q_factor: float = 0.70710678) -> np.ndarray:
+    x = np.ascontiguousarray(samples, dtype=np.int16)
+    y = np.zeros(x.size, dtype=np.float64)
+    lib().bdo_biquad_filter_f64(_vp(x), x.size, sampling_rate, cutoff_hz, q_factor, _vp(y))
+    return y
