@@ -106,7 +106,7 @@ class BiquadDesign(C.Structure):
     """bd_biquad_design of include/beat_detector_hip.h (extension analysis)."""
 
     _fields_ = [("b0", C.c_float), ("b1", C.c_float), ("b2", C.c_float), ("na1", C.c_float), ("na2", C.c_float),
-                ("pw", (C.c_float * 4) * 6), ("q", (C.c_float * 4) * 64)]
+                ("c1b", C.c_float), ("c2b", C.c_float), ("pw", (C.c_float * 4) * 6), ("q", (C.c_float * 4) * 64)]
 
 
 class BiquadParams(C.Structure):

@@ -8,8 +8,8 @@
 //     contiguous input: coalesced 16-byte loads, transposed through a private LDS
 //     tile (144-byte rows: conflict-free ds_write_b128 / ds_read_b128) so that lane
 //     l owns chunk l; the next step's loads are in flight during the arithmetic;
-//   * pass 1: FIR part u[n] and the zero-state response of the chunk (u stays in
-//     registers);
+//   * pass 1: FIR part u[n] and the zero-state response of the chunk, two samples per
+//     step of the recurrence (packed fmas; u stays in registers);
 //   * Hillis-Steele scan over the 64 chunk responses with the precomputed powers
 //     P^(2^k) of the chunk transition, then e_l = P^(l+1) s_in + v_l gives the state
 //     at every chunk boundary; s_in is carried from step to step in the wavefront;
@@ -22,6 +22,9 @@
 #include "bd_internal.h"
 
 #define BD_BQ_ROW 36 /* dwords per LDS row: 128 B of samples + 16 B pad */
+#ifndef BD_BQ_WAVES
+#define BD_BQ_WAVES 4 /* wavefronts per SIMD the register budget is sized for */
+#endif
 
 struct bd_bq_args {
     const int16_t *samples;
@@ -48,7 +51,31 @@ __device__ __forceinline__ void bd_bq_affine(const float m0, const float m1, con
     ob = __builtin_fmaf(m3, vb, __builtin_fmaf(m2, va, wb));
 }
 
-__global__ __launch_bounds__(256) void bd_biquad_env_kernel(bd_bq_args a)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// Two samples of the recurrence from prev = (y[2i-2], y[2i-1]):
+//   y[2i]   = fma(na1, p1, fma(na2, p2, u[2i]))
+//   y[2i+1] = fma(c1b, p1, fma(c2b, p2, w_i)),  w_i = fma(na1, u[2i], u[2i+1])
+// as two packed fmas; c2 = (na2, c2b), c1 = (na1, c1b) (uniform: scalar register pairs),
+// uw = (u[2i], w_i).  The op_sel modifiers broadcast one half of `prev` (the compiler does
+// not form them).
+// m = max(m, |p.x|, |p.y|).  Assembly, because the optimizer otherwise re-associates the
+// chain of maxima into a tree evaluated after the loop and keeps every operand alive.
+__device__ __forceinline__ void bd_bq_absmax(float &m, v2f p)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(p.x), "v"(p.y));
+}
+
+__device__ __forceinline__ v2f bd_bq_pair(v2f c1, v2f c2, v2f prev, v2f uw)
+{
+    v2f y;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %4, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "=&v"(y) : "s"(c2), "v"(prev), "v"(uw), "s"(c1));
+    return y;
+}
+
+__global__ __launch_bounds__(256, BD_BQ_WAVES) void bd_biquad_env_kernel(bd_bq_args a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t tile_all[4][64 * BD_BQ_ROW];
     __shared__ float out_v[4][128];
@@ -64,18 +91,29 @@ __global__ __launch_bounds__(256) void bd_biquad_env_kernel(bd_bq_args a)
     const uint64_t last_unit = a.n_used / 8 - 1; // last 16-byte unit that belongs to a window
 
     const float b0 = a.d.b0, b1 = a.d.b1, b2 = a.d.b2, na1 = a.d.na1, na2 = a.d.na2;
-    const float q0 = a.d.q[lane][0], q1 = a.d.q[lane][1], q2 = a.d.q[lane][2], q3 = a.d.q[lane][3];
+    const v2f c1v = v2f{na1, a.d.c1b}, c2v = v2f{na2, a.d.c2b};
+    const v2f b0v = v2f{b0, b0}, b2v = v2f{b2, b2};
 
-    // loads of one step: unit j * 64 + lane of the step's 512 units.  Units past the
-    // analysed range are replaced by the last valid one: their chunks are never reported
-    // and cannot influence earlier ones.
+    // loads of one step: 16-byte unit j * 64 + lane of the step's 512 units.  A step that
+    // lies inside the analysed range loads from one base address; in the last, partial step
+    // units past the range are replaced by the last valid one (their chunks are never
+    // reported and cannot influence earlier ones).
     uint4 ld[8];
+    auto load_step = [&](uint64_t st) {
+        if ((st + 1) * 4096 <= a.n_used) {
+            const int16_t *base = sp + st * 4096 + lane * 8;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        uint64_t unit = (uint64_t)(j * 64 + lane);
-        unit = unit < last_unit ? unit : last_unit;
-        ld[j] = bd_load_stream16(sp + unit * 8);
-    }
+            for (int j = 0; j < 8; j++) ld[j] = bd_load_stream16(base + j * 512);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint64_t unit = st * 512 + (uint64_t)(j * 64 + lane);
+                unit = unit < last_unit ? unit : last_unit;
+                ld[j] = bd_load_stream16(sp + unit * 8);
+            }
+        }
+    };
+    load_step(0);
     uint4 *wr = reinterpret_cast<uint4 *>(tile + (lane >> 3) * BD_BQ_ROW + (lane & 7) * 4); // + j * 8 rows
     const uint4 *rd = reinterpret_cast<const uint4 *>(tile + lane * BD_BQ_ROW);
 
@@ -96,37 +134,33 @@ __global__ __launch_bounds__(256) void bd_biquad_env_kernel(bd_bq_args a)
             const uint4 r = rd[c];
             raw[4 * c] = r.x; raw[4 * c + 1] = r.y; raw[4 * c + 2] = r.z; raw[4 * c + 3] = r.w;
         }
-        if (st + 1 < n_steps) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint64_t unit = (st + 1) * 512 + (uint64_t)(j * 64 + lane);
-                unit = unit < last_unit ? unit : last_unit;
-                ld[j] = bd_load_stream16(sp + unit * 8);
-            }
-        }
         // the two samples before the chunk
         uint32_t prevd = (uint32_t)__shfl_up((int)raw[31], 1, 64);
         if (lane == 0) prevd = carry_x;
         carry_x = (uint32_t)__builtin_amdgcn_readlane((int)raw[31], 63);
-        float x1 = (float)(short)(prevd >> 16), x2 = (float)(short)(prevd & 0xffff);
+        v2f xp = v2f{(float)(short)(prevd & 0xffff), (float)(short)(prevd >> 16)}; // (x[n-2], x[n-1])
 
-        // pass 1: FIR part and zero-state response
-        float u[64];
-        float z1 = 0.f, z2 = 0.f, mxf = 0.f;
+        // pass 1: FIR part and zero-state response, two samples per step of the recurrence
+        v2f uw[32];                 // (u[2i], w_i)
+        v2f zp = v2f{0.f, 0.f};     // (z[2i-2], z[2i-1])
+        float mxf = 0.f;
 #pragma unroll
         for (int i = 0; i < 32; i++) {
             const int d = (int)raw[i];
-            const float xa = (float)(short)(d & 0xffff), xb = (float)(short)(d >> 16);
-            u[2 * i] = __builtin_fmaf(b2, x2, __builtin_fmaf(b1, x1, b0 * xa));
-            u[2 * i + 1] = __builtin_fmaf(b2, x1, __builtin_fmaf(b1, xa, b0 * xb));
-            mxf = fmaxf(mxf, fmaxf(__builtin_fabsf(xa), __builtin_fabsf(xb)));
-            const float za = __builtin_fmaf(na2, z2, __builtin_fmaf(na1, z1, u[2 * i]));
-            const float zb = __builtin_fmaf(na2, z1, __builtin_fmaf(na1, za, u[2 * i + 1]));
-            z2 = za; z1 = zb;
-            x2 = xa; x1 = xb;
+            const v2f xc = v2f{(float)(short)(d & 0xffff), (float)(short)(d >> 16)};
+            // u[n] = fma(b1, x[n-1], fma(b2, x[n-2], b0 * x[n])): the b0 and b2 terms of two samples packed
+            const v2f t = __builtin_elementwise_fma(b2v, xp, b0v * xc);
+            const float u0 = __builtin_fmaf(b1, xp.y, t.x), u1 = __builtin_fmaf(b1, xc.x, t.y);
+            uw[i] = v2f{u0, __builtin_fmaf(na1, u0, u1)};
+            bd_bq_absmax(mxf, xc);
+            zp = bd_bq_pair(c1v, c2v, zp, uw[i]);
+            xp = xc;
         }
+        // the raw samples are dead: their registers take the next step's loads, which stay in
+        // flight during the scan and the second pass
+        if (st + 1 < n_steps) load_step(st + 1);
         // scan over the chunk responses
-        float va = z1, vb = z2;
+        float va = zp.y, vb = zp.x;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             const float pa = __shfl_up(va, 1 << k, 64), pb = __shfl_up(vb, 1 << k, 64);
@@ -135,19 +169,18 @@ __global__ __launch_bounds__(256) void bd_biquad_env_kernel(bd_bq_args a)
             if (lane >= (1 << k)) { va = ta; vb = tb; }
         }
         float ea, eb;
-        bd_bq_affine(q0, q1, q2, q3, sa, sb, va, vb, ea, eb);
+        bd_bq_affine(a.d.q[lane][0], a.d.q[lane][1], a.d.q[lane][2], a.d.q[lane][3], sa, sb, va, vb, ea, eb);
         float y1 = __shfl_up(ea, 1, 64), y2 = __shfl_up(eb, 1, 64);
         if (lane == 0) { y1 = sa; y2 = sb; }
         sa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ea), 63));
         sb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eb), 63));
         // pass 2: the chunk from its true start state
         float myf = 0.f;
+        v2f yp = v2f{y2, y1};
 #pragma unroll
         for (int i = 0; i < 32; i++) {
-            const float ya = __builtin_fmaf(na2, y2, __builtin_fmaf(na1, y1, u[2 * i]));
-            const float yb = __builtin_fmaf(na2, y1, __builtin_fmaf(na1, ya, u[2 * i + 1]));
-            myf = fmaxf(myf, fmaxf(__builtin_fabsf(ya), __builtin_fabsf(yb)));
-            y2 = ya; y1 = yb;
+            yp = bd_bq_pair(c1v, c2v, yp, uw[i]);
+            bd_bq_absmax(myf, yp);
         }
         // decision windows: maxima over the lanes of a window
         for (uint32_t o = 1; o < lpw; o <<= 1) {
@@ -212,6 +245,8 @@ extern "C" int bd_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_
     d->b2 = d->b0;
     d->na1 = (float)((2.0 * cw) / a0);
     d->na2 = (float)(-(1.0 - alpha) / a0);
+    d->c1b = (float)((double)d->na1 * (double)d->na1 + (double)d->na2);
+    d->c2b = (float)((double)d->na1 * (double)d->na2);
     const double am[4] = {(double)d->na1, (double)d->na2, 1.0, 0.0};
     double p[4] = {1.0, 0.0, 0.0, 1.0};
     for (int i = 0; i < 64; i++) bd_mat2_mul(am, p, p);

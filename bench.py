@@ -41,6 +41,9 @@ WORKLOADS = {
     "onset_2048": ("Onset", 1024, 4096, 300,
                    "Extension mode: 4,096 synthetic 5-min tracks per GPU, 2048-pt Hann STFT hop 1024, spectral flux + "
                    "band energy + adaptive peak picking"),
+    "biquad": ("Biquad", 1024, 4096, 60,
+               "Extension mode: carried-state biquad envelope (120 Hz low-pass as a chunked scan), 4,096 synthetic "
+               "click-track streams x 60 s @ 44.1 kHz, 1024-sample decision windows + refractory"),
     "onset_1024": ("Onset", 512, 4096, 300,
                    "Extension mode: 4,096 synthetic 5-min tracks per GPU, 1024-pt Hann STFT hop 512, spectral flux + "
                    "band energy + adaptive peak picking"),
@@ -95,7 +98,8 @@ def main() -> None:
     if args.seconds:
         seconds = args.seconds
     onset = kind_name == "Onset"
-    kind = None if onset else bd.StrategyKind[kind_name]
+    biquad = kind_name == "Biquad"
+    kind = None if onset else bd.StrategyKind["LPF" if biquad else kind_name]
     sr = 44100
     n = sr * seconds
     stride = (n + 63) & ~63  # rows start on 128-byte boundaries
@@ -158,8 +162,19 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    bq_params = bd.BiquadParams.default(window_len=L) if biquad else None
+    bq_design = bd.biquad_design(sr, bq_params.cutoff_hz, bq_params.q_factor) if biquad else None
+
+    def stage1_biquad():
+        rc = L_.bd_biquad_envelope(sr, ctypes.byref(bq_params), ctypes.byref(bq_design), samples.data_ptr(), streams, n,
+                                   stride, values.data_ptr(), flags.data_ptr(), out_stride, st)
+        if rc != 0:
+            raise RuntimeError(L_.bd_last_error().decode())
+
     if onset:
         stage1, stage2 = stage1_onset, stage2_onset
+    if biquad:
+        stage1 = stage1_biquad
     for _ in range(args.warmup):
         stage1()
         stage2()
@@ -180,7 +195,7 @@ def main() -> None:
     k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     kernel_name = {"Spectrum": "bd_spectrum_band_kernel", "LPF": "bd_lpf_window_kernel",
-                   "Onset": "bd_stft_flux_kernel"}[kind_name]
+                   "Onset": "bd_stft_flux_kernel", "Biquad": "bd_biquad_env_kernel"}[kind_name]
     total_beats = int(count.sum().item())
 
     if dist is not None:
@@ -273,6 +288,8 @@ def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams):
     cannot be built here) on the first `n_streams` streams of the same batch."""
     if kind_name == "Onset":
         return cpu_baseline_onset(samples, n, L, sr, min(n_streams, 128))
+    if kind_name == "Biquad":
+        return cpu_baseline_biquad(samples, n, L, sr, min(n_streams, 512))
     from oracle import bd_oracle
     okind = bd_oracle.KIND_SPECTRUM if kind_name == "Spectrum" else bd_oracle.KIND_LPF
     host = samples[:n_streams, :n].cpu().numpy()
@@ -299,6 +316,49 @@ def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams):
         "_n": n_streams,
         "value_1core": one * (n / sr) / dt1,
         "sample_1core": f"first {one} streams, 1 thread, {dt1:.1f} s",
+    }
+
+
+def cpu_baseline_biquad(samples, n, L, sr, n_streams):
+    """The CPU definition of the carried-state biquad envelope (oracle/bd_oracle_ext.c)
+    plus the refractory replay, one stream per task."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import bd_oracle, bd_oracle_ext as ox
+    host = samples[:n_streams, :n].cpu().numpy()
+    cores = 16
+    try:
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+    p = ox.biquad_params(window_len=L)
+    d = ox.biquad_design(sr, p.cutoff_hz, p.q_factor)
+    ol = bd_oracle.lib()
+
+    def one(row):
+        _, flags = ox.biquad_envelope(row, sr, p, d)
+        st = bd_oracle.State()
+        ol.bdo_state_new(st, sr)
+        beats = 0
+        for f in flags:
+            ol.bdo_state_update_time(st, L)
+            if f and ol.bdo_last_beat_beyond_threshold(st, 400):
+                ol.bdo_state_mark_beat(st)
+                beats += 1
+        return beats
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(one, host))
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_streams * (n / sr) / dt,
+        "unit": "audio-sec/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n_streams} streams x {n // sr} s of the same batch, {cores} threads, {dt:.1f} s of wall "
+                  f"time; beats found {total} (the definition of the extension analysis; refractory replay in Python)",
+        "cpu_events": int(total),
+        "_n": n_streams,
     }
 
 

@@ -294,7 +294,8 @@ int bd_onset_batch(uint32_t sampling_rate, const bd_onset_params *p, const int16
  * src/lib.rs:133-136.  Results are defined by the CPU definition the tests hold
  * (same f32 operation order: bit-identical), not by the reference. */
 typedef struct bd_biquad_design {
-    float b0, b1, b2, na1, na2;   /* y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])); u = FIR part */
+    float b0, b1, b2, na1, na2;   /* y[n] = na1 y[n-1] + na2 y[n-2] + u[n]; u = FIR part */
+    float c1b, c2b;               /* two-step form: y[n+1] = c1b y[n-1] + c2b y[n-2] + na1 u[n] + u[n+1] */
     float pw[6][4];               /* P^(2^k), k = 0..5; P = state transition over 64 samples (row-major 2x2) */
     float q[64][4];               /* P^(l+1), l = 0..63 */
 } bd_biquad_design;

@@ -243,23 +243,27 @@ size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate
  * 1. Design: RBJ low-pass in float64 (w0 = 2 pi fc / fs, alpha = sin w0 / (2 Q),
  *    b0 = b2 = (1 - cos w0) / 2, b1 = 1 - cos w0, a0 = 1 + alpha, a1 = -2 cos w0,
  *    a2 = 1 - alpha), normalised by a0 and rounded to f32: b0, b1, b2, na1 = -a1/a0,
- *    na2 = -a2/a0.  A = [[na1, na2], [1, 0]] (from the rounded coefficients, as
+ *    na2 = -a2/a0; c1b = na1^2 + na2, c2b = na1 na2 from the rounded coefficients in float64,
+ *    rounded once.  A = [[na1, na2], [1, 0]] (from the rounded coefficients, as
  *    float64), P = A^64; pw[k] = P^(2^k), q[l] = P^(l+1), computed in float64 by
  *    repeated multiplication and rounded to f32.
- * 2. u[n] = fma(b2, x[n-2], fma(b1, x[n-1], b0 * x[n])), x[-1] = x[-2] = 0.
+ * 2. u[n] = fma(b1, x[n-1], fma(b2, x[n-2], b0 * x[n])), x[-1] = x[-2] = 0.
  * 3. The stream is cut into chunks of 64 samples; 64 consecutive chunks form a
  *    step (4096 samples).  A trailing partial step is evaluated with the missing
  *    chunks' input taken as zero (their results are not reported).
- *    Zero-state response of chunk l of a step: z[-1] = z[-2] = 0,
- *    z[n] = fma(na2, z[n-2], fma(na1, z[n-1], u[n])); r_l = (z[63], z[62]).
+ *    The recurrence advances two samples at a time from (p1, p2) = (y[2i-1], y[2i-2]):
+ *        w_i     = fma(na1, u[2i], u[2i+1])
+ *        y[2i]   = fma(na1, p1, fma(na2, p2, u[2i]))
+ *        y[2i+1] = fma(c1b, p1, fma(c2b, p2, w_i))
+ *    Zero-state response of chunk l of a step: z[-1] = z[-2] = 0, z advanced as above;
+ *    r_l = (z[63], z[62]).
  * 4. Inclusive scan over the 64 chunks of a step (Hillis-Steele, k = 0..5):
  *    v_l <- M_k v_{l - 2^k} + v_l for l >= 2^k, with M_k = pw[k] and
  *    (M v + w).a = fma(M01, v.b, fma(M00, v.a, w.a)), .b = fma(M11, v.b, fma(M10, v.a, w.b)).
  * 5. State at the end of chunk l: e_l = q[l] s_in + v_l (same fma pattern), where
  *    s_in is the state at the start of the step (zero for the first step, e_63 of
  *    the previous step otherwise).  Chunk l starts from s_l = e_{l-1} (s_0 = s_in).
- * 6. Output of chunk l: y[-1] = s_l.a, y[-2] = s_l.b,
- *    y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])).
+ * 6. Output of chunk l: y[-1] = s_l.a, y[-2] = s_l.b, y advanced as in item 3.
  * 7. Per complete window: m = max |x| with -32768 counted as 32767; value = max |y|;
  *    thr = (int)(ratio * (float)m) (truncation); flag = m >= min_amplitude && value >= (float)thr.
  * ====================================================================== */
@@ -287,6 +291,8 @@ int bdo_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_hz, float 
     d->b2 = d->b0;
     d->na1 = (float)((2.0 * cw) / a0);
     d->na2 = (float)(-(1.0 - alpha) / a0);
+    d->c1b = (float)((double)d->na1 * (double)d->na1 + (double)d->na2);
+    d->c2b = (float)((double)d->na1 * (double)d->na2);
     const double a[4] = {(double)d->na1, (double)d->na2, 1.0, 0.0};
     double p[4] = {1.0, 0.0, 0.0, 1.0};
     for (int i = 0; i < BDO_BQ_CHUNK; i++) mat2_mul(a, p, p);           /* P = A^64 */
@@ -327,14 +333,17 @@ int bdo_biquad_envelope(const int16_t *samples, size_t n_samples, const bdo_biqu
             const float x0 = n < n_used ? (float)samples[n] : 0.0f;
             const float x1 = (n >= 1 && n - 1 < n_used) ? (float)samples[n - 1] : 0.0f;
             const float x2 = (n >= 2 && n - 2 < n_used) ? (float)samples[n - 2] : 0.0f;
-            u[i] = fmaf(d->b2, x2, fmaf(d->b1, x1, d->b0 * x0));
+            u[i] = fmaf(d->b1, x1, fmaf(d->b2, x2, d->b0 * x0));
         }
         float va[64], vb[64];
         for (int l = 0; l < 64; l++) {        /* item 3 */
             float z1 = 0.0f, z2 = 0.0f;
-            for (int i = 0; i < BDO_BQ_CHUNK; i++) {
-                const float z = fmaf(d->na2, z2, fmaf(d->na1, z1, u[l * BDO_BQ_CHUNK + i]));
-                z2 = z1; z1 = z;
+            for (int i = 0; i < BDO_BQ_CHUNK; i += 2) {
+                const float u0 = u[l * BDO_BQ_CHUNK + i], u1 = u[l * BDO_BQ_CHUNK + i + 1];
+                const float w = fmaf(d->na1, u0, u1);
+                const float za = fmaf(d->na1, z1, fmaf(d->na2, z2, u0));
+                const float zb = fmaf(d->c1b, z1, fmaf(d->c2b, z2, w));
+                z2 = za; z1 = zb;
             }
             va[l] = z1; vb[l] = z2;
         }
@@ -350,10 +359,13 @@ int bdo_biquad_envelope(const int16_t *samples, size_t n_samples, const bdo_biqu
         for (int l = 0; l < 64; l++) affine2(d->q[l], sa, sb, va[l], vb[l], &ea[l], &eb[l]);   /* item 5 */
         for (int l = 0; l < 64; l++) {        /* item 6 */
             float y1 = l ? ea[l - 1] : sa, y2 = l ? eb[l - 1] : sb;
-            for (int i = 0; i < BDO_BQ_CHUNK; i++) {
-                const float v = fmaf(d->na2, y2, fmaf(d->na1, y1, u[l * BDO_BQ_CHUNK + i]));
-                y[l * BDO_BQ_CHUNK + i] = v;
-                y2 = y1; y1 = v;
+            for (int i = 0; i < BDO_BQ_CHUNK; i += 2) {
+                const float u0 = u[l * BDO_BQ_CHUNK + i], u1 = u[l * BDO_BQ_CHUNK + i + 1];
+                const float w = fmaf(d->na1, u0, u1);
+                const float ya = fmaf(d->na1, y1, fmaf(d->na2, y2, u0));
+                const float yb = fmaf(d->c1b, y1, fmaf(d->c2b, y2, w));
+                y[l * BDO_BQ_CHUNK + i] = ya; y[l * BDO_BQ_CHUNK + i + 1] = yb;
+                y2 = ya; y1 = yb;
             }
         }
         sa = ea[63]; sb = eb[63];

@@ -64,7 +64,8 @@ size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate
  * the arithmetic specification. */
 #define BDO_BQ_CHUNK 64
 typedef struct bdo_biquad_design {
-    float b0, b1, b2, na1, na2;   /* y[n] = fma(na2, y[n-2], fma(na1, y[n-1], u[n])), u = FIR part */
+    float b0, b1, b2, na1, na2;   /* y[n] = na1 y[n-1] + na2 y[n-2] + u[n], u = FIR part */
+    float c1b, c2b;               /* two-step form: y[n+1] = c1b y[n-1] + c2b y[n-2] + na1 u[n] + u[n+1] */
     float pw[6][4];               /* P^(2^k), k = 0..5, P = state transition over one chunk; row-major 2x2 */
     float q[64][4];               /* P^(l+1), l = 0..63 */
 } bdo_biquad_design;
