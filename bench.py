@@ -256,6 +256,8 @@ def main() -> None:
         },
     }
 
+    if result["roofline"].get("note") is None:
+        result["roofline"].pop("note", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(bd, kind_name, samples, n, L, sr, min(args.cpu_streams, streams))
         # the GPU's count over the same streams (equal counts are a full-size consistency check, not the parity test)
