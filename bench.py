@@ -216,7 +216,9 @@ def main() -> None:
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
 
     result = {
-        "metric": "audio-sec analysed/sec (node), %d-pt STFT" % (2 * L if onset else 1024),
+        "metric": "audio-sec analysed/sec (node), " + {"Spectrum": "1024-pt STFT", "Onset": "%d-pt STFT" % (2 * L),
+                                                       "LPF": "lowpass windows",
+                                                       "Biquad": "carried-state biquad"}[kind_name],
         "value": value,
         "unit": "audio-sec/s",
         "n_gpus": world,
@@ -256,6 +258,15 @@ def main() -> None:
         },
     }
 
+    if onset:
+        # a full FFT per frame is bounded by f32 vector throughput as well: 2.5 N log2 N flops per real FFT
+        # against the packed-FMA vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2 at 2.4 GHz)
+        nfft = 2 * L
+        flops = streams * n_cb * 2.5 * nfft * (nfft.bit_length() - 1)
+        peak_tflops = 256 * 4 * 16 * 2 * 2 * 2.4e9 / 1e12
+        result["roofline"]["valu"] = {"achieved": flops / (k1_ms * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s",
+                                      "frac": flops / (k1_ms * 1e-3) / 1e12 / peak_tflops,
+                                      "flops_per_frame": 2.5 * nfft * (nfft.bit_length() - 1)}
     if result["roofline"].get("note") is None:
         result["roofline"].pop("note", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
