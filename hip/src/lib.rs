@@ -5,7 +5,7 @@
 //!
 //! The parent crate keeps its `Strategy` trait, `StrategyKind` enum and
 //! `record::start_listening` signature; `StrategyKind::detector` returns a
-//! type that wraps [`Detector`] (see INTEGRATION.md).
+//! type that wraps [`Detector`].
 #![allow(non_camel_case_types)]
 
 use std::ffi::CStr;

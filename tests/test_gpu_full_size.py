@@ -1,0 +1,86 @@
+"""The benchmark's full-size batches, checked on sampled streams.
+
+The oracle cannot finish 16,384 streams in a test, but it finishes a stream of
+the same length in milliseconds: streams spread over the batch (first, last,
+run and block boundaries) must come out exactly as the oracle computes them
+alone, which also shows that a stream's result does not depend on its batch."""
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+SR = 44100
+
+
+def _batch(bd, n_streams, seconds, seed=0x5EED):
+    import torch
+    n = SR * seconds
+    buf = torch.empty((n_streams, (n + 63) & ~63), dtype=torch.int16, device="cuda")
+    bd.synth_fill(buf, n_samples=n, seed=seed, sampling_rate=SR)
+    return buf, n
+
+
+def _sample(n_streams):
+    picks = {0, 1, 3, 4, 5, 63, 64, 255, 256, n_streams // 2, n_streams - 2, n_streams - 1}
+    return sorted(p for p in picks if 0 <= p < n_streams)
+
+
+def test_spectrum_hop512_16384_streams(bd, oracle):
+    import torch
+    buf, n = _batch(bd, 16384, 60)
+    res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, buf, 512, n_samples=n)
+    torch.cuda.synchronize()
+    assert res.flags.shape == (16384, 5167)
+    for s in _sample(16384):
+        row = buf[s, :n].cpu().numpy()
+        v, c, beats = oracle.run_stream(oracle.KIND_SPECTRUM, SR, row, 512, full=True)
+        got = res.values[s].cpu().numpy()
+        assert (np.abs(got - v) <= util.value_tolerance(v, 32768, 3)).all(), s
+        adjacent = util.threshold_adjacent(v, 2.1e6)
+        assert ((res.flags[s].cpu().numpy() == c) | adjacent).all(), s
+        if not adjacent.any():
+            assert res.beats(s) == beats, s
+    del res, buf
+    torch.cuda.empty_cache()
+
+
+def test_lpf_4096_streams(bd, oracle):
+    import torch
+    buf, n = _batch(bd, 4096, 60)
+    res = bd.analyze_batch(bd.StrategyKind.LPF, SR, buf, 1024, n_samples=n)
+    torch.cuda.synchronize()
+    for s in _sample(4096):
+        row = buf[s, :n].cpu().numpy()
+        v, c, beats = oracle.run_stream(oracle.KIND_LPF, SR, row, 1024, full=True)
+        assert np.array_equal(res.values[s].cpu().numpy(), v), s
+        assert np.array_equal(res.flags[s].cpu().numpy(), c), s
+        assert res.beats(s) == beats, s
+    del res, buf
+    torch.cuda.empty_cache()
+
+
+def test_extension_batches(bd, oracle_ext):
+    """Extension analyses at their benchmark shapes (bit-identical to their definitions)."""
+    import torch
+    buf, n = _batch(bd, 4096, 60)
+    vals, flags = bd.biquad_envelope(SR, buf, n_samples=n)
+    torch.cuda.synchronize()
+    for s in _sample(4096):
+        v, f = oracle_ext.biquad_envelope(buf[s, :n].cpu().numpy(), SR)
+        assert np.array_equal(vals[s].cpu().numpy().view(np.uint32), v.view(np.uint32)), s
+        assert np.array_equal(flags[s].cpu().numpy(), f), s
+    del vals, flags, buf
+    torch.cuda.empty_cache()
+    buf, n = _batch(bd, 1024, 300)
+    res = bd.onset_batch(SR, buf, n_samples=n, max_onsets=4096)
+    torch.cuda.synchronize()
+    assert res.flux.shape == (1024, 12918)
+    for s in _sample(1024)[::2]:
+        flux, band = oracle_ext.onset_stft(buf[s, :n].cpu().numpy(), SR)
+        assert np.array_equal(res.flux[s].cpu().numpy().view(np.uint32), flux.view(np.uint32)), s
+        assert np.array_equal(res.band_energy[s].cpu().numpy().view(np.uint32), band.view(np.uint32)), s
+        _, frame, ms = oracle_ext.onset_pick(flux, SR)
+        assert res.onsets(s) == list(zip(frame.tolist(), ms.tolist())), s
+    del res, buf
+    torch.cuda.empty_cache()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Latency of the live path (BASELINE config 5): 256 concurrent streams,
+"""Latency of the live path (the live low-latency configuration): 256 concurrent streams,
 1024-sample callbacks, one HIP graph replay per tick.  Prints one JSON line with
 p50/p99 of submit -> result-on-host latency and the real-time margin."""
 import json, os, sys, time
