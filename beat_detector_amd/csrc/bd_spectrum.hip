@@ -321,10 +321,10 @@ __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generi
 
 // ---- launcher ---------------------------------------------------------------
 template <int MODE, int NK>
-static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, hipStream_t st)
+static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, unsigned lds_pad, hipStream_t st)
 {
-    if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true>), dim3(grid), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false>), dim3(grid), dim3(256), 0, st, a);
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true>), dim3(grid), dim3(256), lds_pad, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false>), dim3(grid), dim3(256), lds_pad, st, a);
 }
 
 int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
@@ -358,16 +358,20 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         const uint64_t grid64 = (a.n_tasks + 3) / 4;
         if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
         const unsigned grid = (unsigned)grid64;
+        // unused dynamic LDS caps the workgroups resident per CU (tuning knob, read at every launch)
+        const char *pad_env = getenv("BD_SPEC_LDS_PAD");
+        unsigned lds_pad = pad_env ? (unsigned)atoi(pad_env) : 0;
+        if (lds_pad > 150000) lds_pad = 150000;
         const int nk = plan.last_bin; // bins 1..last_bin
         const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
         if (callback_len == 512) {
-            if (nk == 0) launch_fast<0, 0>(nyq, a, grid, st);
-            else if (nk == 1) launch_fast<0, 1>(nyq, a, grid, st);
-            else launch_fast<0, 2>(nyq, a, grid, st);
+            if (nk == 0) launch_fast<0, 0>(nyq, a, grid, lds_pad, st);
+            else if (nk == 1) launch_fast<0, 1>(nyq, a, grid, lds_pad, st);
+            else launch_fast<0, 2>(nyq, a, grid, lds_pad, st);
         } else {
-            if (nk == 0) launch_fast<1, 0>(nyq, a, grid, st);
-            else if (nk == 1) launch_fast<1, 1>(nyq, a, grid, st);
-            else launch_fast<1, 2>(nyq, a, grid, st);
+            if (nk == 0) launch_fast<1, 0>(nyq, a, grid, lds_pad, st);
+            else if (nk == 1) launch_fast<1, 1>(nyq, a, grid, lds_pad, st);
+            else launch_fast<1, 2>(nyq, a, grid, lds_pad, st);
         }
         bd_set_last_kernel("bd_spectrum_band_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");

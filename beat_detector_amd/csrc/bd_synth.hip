@@ -134,3 +134,35 @@ extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, voi
                        (hipStream_t)hip_stream, in, out, n);
     return bd_check_hip(hipGetLastError(), "launch bd_f32_to_i16_kernel");
 }
+
+// ---- read-bandwidth probe -----------------------------------------------------
+// The ceiling the sample-streaming kernels are measured against: the same 16-byte
+// non-temporal loads (4 per lane in flight, 256 contiguous bytes per 16 lanes), no
+// arithmetic beyond an xor, one dword written per wavefront.
+__global__ __launch_bounds__(256) void bd_probe_read_kernel(const uint4 *src, uint64_t n_units, uint32_t *sink)
+{
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * 256) >> 6;
+    const int lane = threadIdx.x & 63;
+    uint32_t acc = 0;
+    // a wavefront reads 4 KB (256 units) per step, steps strided by the number of wavefronts
+    for (uint64_t base = wave * 256; base + 256 <= n_units; base += n_waves * 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = bd_load_stream16(src + base + 64 * c + lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc ^= v[c].x ^ v[c].y ^ v[c].z ^ v[c].w;
+    }
+    acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)bd_row_sum((int)acc));
+    if (lane == 0 && sink) sink[wave] = acc;
+}
+
+extern "C" int bd_probe_read(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu, void *hip_stream)
+{
+    if (!src || ((uintptr_t)src % 16)) { bd_set_error("bd_probe_read: src must be a 16-byte aligned device pointer"); return BD_ERR_INVALID_ARG; }
+    if (waves_per_cu == 0 || waves_per_cu > 32) waves_per_cu = 16;
+    const unsigned grid = 256u * waves_per_cu / 4u; // 256 CUs, 4 wavefronts per block
+    hipLaunchKernelGGL(bd_probe_read_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream,
+                       reinterpret_cast<const uint4 *>(src), bytes / 16, sink);
+    return bd_check_hip(hipGetLastError(), "launch bd_probe_read_kernel");
+}

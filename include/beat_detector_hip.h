@@ -321,6 +321,11 @@ int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params *params, c
 /* Name and grid of the dominant kernel of the last bd_analyze_batch call on
  * this thread (for profilers). */
 const char *bd_last_kernel_name(void);
+/* Read-bandwidth probe: streams `bytes` of device memory through the same kind of
+ * loads the analysis kernels use and does nothing else; timing it gives the
+ * ceiling those kernels are compared with.  `sink` (device, 256 * waves_per_cu
+ * dwords, may be NULL) receives one word per wavefront. */
+int bd_probe_read(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu, void *hip_stream);
 
 #ifdef __cplusplus
 }

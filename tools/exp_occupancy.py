@@ -1,0 +1,27 @@
+"""Spectrum hop-512 kernel time against the number of resident workgroups per CU
+(BD_SPEC_LDS_PAD caps it through unused dynamic LDS) and the run length."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import beat_detector_amd as bd
+from beat_detector_amd.api import _out_rows
+streams = 16384; sr = 44100; n = sr * 60; L = 512; stride = (n + 63) & ~63
+n_cb = n // L
+K = bd.StrategyKind.Spectrum
+buf = torch.empty((streams, stride), dtype=torch.int16, device="cuda")
+bd.synth_fill(buf, n_samples=n, seed=1)
+vals = _out_rows(streams, n_cb, torch.float32, "cuda"); flags = _out_rows(streams, n_cb, torch.uint8, "cuda")
+def t():
+    for _ in range(2): bd.batch_candidates(K, sr, buf, L, n_samples=n, values=vals, flags=flags)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(4): bd.batch_candidates(K, sr, buf, L, n_samples=n, values=vals, flags=flags)
+    b.record(); torch.cuda.synchronize()
+    return round(a.elapsed_time(b) / 4, 2)
+out = []
+for pad in (0, 10000, 22000, 30000, 43000, 70000, 0):
+    os.environ["BD_SPEC_LDS_PAD"] = str(pad)
+    for run in (128, 512):
+        os.environ["BD_SPEC_RUN"] = str(run)
+        out.append((pad, run, t()))
+print("lds_pad, run, ms:", out, flush=True)
