@@ -336,7 +336,8 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0);
     const bool fast_len = callback_len == 512 || callback_len == 1024;
     const bool fast_bins = plan.last_bin <= 2;
-    if (aligned && fast_len && fast_bins) {
+    // BD_SPEC_FORCE_GRANULE=1 routes 512 / 1024 to the granule kernel as well (A/B experiments)
+    if (aligned && fast_len && fast_bins && !getenv("BD_SPEC_FORCE_GRANULE")) {
         bd_spec_args a;
         a.samples = samples; a.values = values; a.flags = flags;
         a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;
@@ -376,6 +377,10 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         bd_set_last_kernel("bd_spectrum_band_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");
     }
+    // other multiples of 64 up to 4096: the granule kernel (BD_SPEC_NO_GRANULE=1 forces the generic one)
+    if (aligned && fast_bins && callback_len % 64 == 0 && callback_len <= 4096 && !getenv("BD_SPEC_NO_GRANULE"))
+        return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
+                                          out_stride, st);
     bd_spec_generic_args a;
     a.samples = samples; a.values = values; a.flags = flags;
     a.stride = stride; a.n_cb = n_cb; a.n_total = n_streams * n_cb; a.out_stride = out_stride;

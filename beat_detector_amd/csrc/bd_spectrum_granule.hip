@@ -1,0 +1,274 @@
+// Spectrum strategy, batched, for callback lengths that are multiples of 64
+// samples (up to 4096) other than the two the half-block kernel covers: the value
+// of src/strategies/spectrum.rs:82-92 -- largest magnitude among the bins <= 90 Hz
+// of the 1024-point DFT of the latest 1024 samples -- and the decision of
+// spectrum.rs:77-92, one HBM read per sample.
+//
+// The stream is cut into granules of 64 samples; the ring of a callback is the 16
+// granules that end with it.  With P_k(g) = sum_{n<64} x[64 g + n] w^{k n},
+// w = exp(2 pi i / 1024) (the conjugate of the DFT kernel: magnitudes are the same),
+//     X_k(e) = sum_{i<16} w^{64 k i} P_k(e - 15 + i)
+// is built by four doubling levels
+//     Q^{j+1}(e) = Q^{j}(e - 2^j) + w^{64 k 2^j} Q^{j}(e),     Q^0 = P,  X = Q^4,
+// so every granule is transformed once however the callbacks overlap the ring.
+//
+// One wavefront walks consecutive steps of 64 granules (8 KB) of one stream: coalesced
+// 16-byte loads, transposed through a private LDS tile (144-byte rows, conflict-free)
+// so that lane l owns granule l; per-lane pruned DFT with compile-time twiddles; the
+// doubling levels fetch lane l - 2^j from this step or, for the first lanes, from the
+// values the previous step left in registers.  The amplitude gate (max |x| over the
+// callback's own granules) is a sliding maximum built the same way.  Lanes whose
+// granule ends a callback finish it; results are compacted, staged in LDS and stored
+// contiguously.  A run that does not start the stream first replays the step before it.
+#include "bd_internal.h"
+#include "bd_granule_tw.inc"
+
+#define BD_GR_ROW 36 /* dwords per LDS row: 128 B of samples + 16 B pad */
+
+typedef short bd_gr_short2 __attribute__((ext_vector_type(2)));
+
+struct bd_gr_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride, out_stride, n_cb, n_tasks;
+    uint64_t       n_gran;          // granules that belong to callbacks = n_cb * m
+    uint32_t       m;               // granules per callback (1 .. 64)
+    uint32_t       steps_per_run, runs_per_stream;
+    uint32_t       min_amp, include_dc;
+    float          divisor, threshold;
+};
+
+__device__ __forceinline__ void bd_gr_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// running maximum of magnitudes, kept in program order (the optimizer would re-associate
+// a chain of fmaxf into a tree after the loop and keep every operand alive)
+__device__ __forceinline__ void bd_gr_absmax(float &m, float a, float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+}
+
+// value of lane (l - d) of this step, or of lane (l - d + 64) of the previous step
+__device__ __forceinline__ float bd_gr_back(float cur, float prev, int lane, int d)
+{
+    const int src = (lane - d) & 63;
+    const float c = __shfl(cur, src, 64), p = __shfl(prev, src, 64);
+    return lane >= d ? c : p;
+}
+__device__ __forceinline__ int bd_gr_back(int cur, int prev, int lane, int d)
+{
+    const int src = (lane - d) & 63;
+    const int c = __shfl(cur, src, 64), p = __shfl(prev, src, 64);
+    return lane >= d ? c : p;
+}
+
+template <int NK, bool NYQ>
+__global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t tile_all[4][64 * BD_GR_ROW];
+    __shared__ float out_v[4][128];
+    __shared__ uint8_t out_f[4][128];
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    if (task >= a.n_tasks) return;
+    const uint64_t s = task / a.runs_per_stream;
+    const uint64_t r = task - s * a.runs_per_stream;
+    uint32_t *tile = tile_all[wave];
+    const int16_t *sp = a.samples + s * a.stride;
+    const uint64_t n_steps = (a.n_gran + 63) / 64;
+    const uint64_t st0 = r * a.steps_per_run;
+    const uint64_t st1 = st0 + a.steps_per_run < n_steps ? st0 + a.steps_per_run : n_steps;
+    const uint64_t st_first = st0 > 0 ? st0 - 1 : 0;   // replayed step: fills the "previous step" values
+    const uint64_t last_unit = a.n_gran * 8 - 1;        // last 16-byte unit that belongs to a callback
+    const uint32_t m = a.m;
+    // sliding maximum over m granules = two overlapping windows of 2^lg granules
+    const int lg = 31 - __builtin_clz(m);
+    const int tail = (int)m - (1 << lg);
+
+    uint4 ld[8];
+    auto load_step = [&](uint64_t st) {
+        if ((st + 1) * 64 <= a.n_gran) {
+            const int16_t *base = sp + st * 4096 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ld[j] = bd_load_stream16(base + j * 512);
+        } else { // units past the analysed range are replaced by the last valid one (never reported)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint64_t unit = st * 512 + (uint64_t)(j * 64 + lane);
+                unit = unit < last_unit ? unit : last_unit;
+                ld[j] = bd_load_stream16(sp + unit * 8);
+            }
+        }
+    };
+    load_step(st_first);
+    uint4 *wr = reinterpret_cast<uint4 *>(tile + (lane >> 3) * BD_GR_ROW + (lane & 7) * 4); // + j * 8 rows
+    const uint4 *rd = reinterpret_cast<const uint4 *>(tile + lane * BD_GR_ROW);
+
+    // values of the previous step, per doubling level (zero = silence before the stream)
+    float p_re[4][NK > 0 ? NK : 1], p_im[4][NK > 0 ? NK : 1], p_amax[6];
+    int p_dc[4], p_ny[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        p_dc[j] = 0; p_ny[j] = 0;
+#pragma unroll
+        for (int k = 0; k < (NK > 0 ? NK : 1); k++) { p_re[j][k] = 0.f; p_im[j][k] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) p_amax[j] = 0.f;
+    float p_amax_top = 0.f;                              // level lg of the previous step
+
+    uint32_t pend = 0;                                   // results staged in LDS
+    uint64_t cb_base = (st0 * 64) / m;                   // callbacks that end before this run
+
+    for (uint64_t st = st_first; st < st1; st++) {
+        bd_gr_sync();
+#pragma unroll
+        for (int j = 0; j < 8; j++) wr[j * 8 * (BD_GR_ROW / 4)] = ld[j];
+        bd_gr_sync();
+        uint32_t raw[32];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint4 q = rd[c];
+            raw[4 * c] = q.x; raw[4 * c + 1] = q.y; raw[4 * c + 2] = q.z; raw[4 * c + 3] = q.w;
+        }
+        if (st + 1 < st1) load_step(st + 1);
+
+        // pruned DFT of the lane's granule
+        float re[NK > 0 ? NK : 1], im[NK > 0 ? NK : 1], amax = 0.f;
+        int dc = 0, ny = 0;
+#pragma unroll
+        for (int k = 0; k < (NK > 0 ? NK : 1); k++) { re[k] = 0.f; im[k] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int v = (int)raw[i];
+            const float x0 = (float)(short)(v & 0xffff), x1 = (float)(short)(v >> 16);
+            dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_gr_short2, v), bd_gr_short2{1, 1}, dc, false);
+            if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_gr_short2, v), bd_gr_short2{1, -1}, ny, false);
+            bd_gr_absmax(amax, x0, x1);
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                re[k] = __builtin_fmaf(x0, BD_GR_C[k][2 * i], re[k]);     im[k] = __builtin_fmaf(x0, BD_GR_S[k][2 * i], im[k]);
+                re[k] = __builtin_fmaf(x1, BD_GR_C[k][2 * i + 1], re[k]); im[k] = __builtin_fmaf(x1, BD_GR_S[k][2 * i + 1], im[k]);
+            }
+        }
+        // doubling levels: 1 -> 16 granules
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int d = 1 << j;
+            const int b_dc = bd_gr_back(dc, p_dc[j], lane, d);
+            p_dc[j] = dc;
+            dc = b_dc + dc;
+            if (NYQ) {
+                const int b_ny = bd_gr_back(ny, p_ny[j], lane, d);
+                p_ny[j] = ny;
+                ny = b_ny + ny;
+            }
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const float b_re = bd_gr_back(re[k], p_re[j][k], lane, d), b_im = bd_gr_back(im[k], p_im[j][k], lane, d);
+                p_re[j][k] = re[k]; p_im[j][k] = im[k];
+                const float c = BD_GRL_C[k][j], sn = BD_GRL_S[k][j];
+                const float nr = b_re + (c * re[k] - sn * im[k]);
+                const float ni = b_im + (c * im[k] + sn * re[k]);
+                re[k] = nr; im[k] = ni;
+            }
+        }
+        // amplitude gate: maximum over the callback's own m granules (lg doubling levels, then
+        // two overlapping windows of 2^lg granules)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            if (j < lg) {
+                const float b = bd_gr_back(amax, p_amax[j], lane, 1 << j);
+                p_amax[j] = amax;
+                amax = fmaxf(amax, b);
+            }
+        }
+        float gate_max = amax;
+        if (tail > 0) gate_max = fmaxf(amax, bd_gr_back(amax, p_amax_top, lane, tail));
+        p_amax_top = amax;
+
+        // lanes whose granule ends a callback finish it
+        const uint64_t g = st * 64 + (uint64_t)lane;
+        const bool ends = st >= st0 && g < a.n_gran && (g + 1) % m == 0;
+        float value = 0.f;
+        bool flag = false;
+        {
+            const float x_dc = (float)dc;
+            float m0 = fabsf(x_dc);
+            if (NYQ) {
+                const float x_ny = (float)ny;
+                m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
+            }
+            float best = a.include_dc ? m0 : 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; k++) best = fmaxf(best, sqrtf(re[k] * re[k] + im[k] * im[k]));
+            value = (a.divisor == 0.f) ? best : best / a.divisor;
+            flag = fminf(gate_max, 32767.f) >= (float)a.min_amp && value > a.threshold;
+        }
+        const unsigned long long mask = __ballot(ends);
+        if (ends) {
+            const uint32_t slot = pend + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            out_v[wave][slot] = value;
+            out_f[wave][slot] = flag ? 1 : 0;
+        }
+        pend += (uint32_t)__builtin_popcountll(mask);
+        if (pend >= 64 || st + 1 == st1) {
+            bd_gr_sync();
+            const uint64_t o0 = s * a.out_stride + cb_base;
+            if (a.values) {
+                __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values + o0, pend * 4u);
+                for (unsigned i = lane; i < pend; i += 64) bd_store_stream_f32(rv, i * 4u, out_v[wave][i]);
+            }
+            __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, pend);
+            for (unsigned i = lane; i < pend; i += 64) bd_store_stream_u8(rf, i, out_f[wave][i]);
+            cb_base += pend;
+            pend = 0;
+        }
+    }
+}
+
+template <int NK>
+static void bd_gr_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+{
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, true>), dim3(grid), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
+// Returns BD_OK after enqueueing, or a negative status; the caller has checked that
+// callback_len is a multiple of 64 not above 4096, rows are 16-byte aligned and the kept
+// bins are 0 .. last_bin <= 2.
+int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                               uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
+                               uint64_t out_stride, hipStream_t st)
+{
+    bd_gr_args a;
+    a.samples = samples; a.values = values; a.flags = flags;
+    a.stride = stride; a.out_stride = out_stride;
+    a.n_cb = n_samples / callback_len;
+    a.m = callback_len / 64;
+    a.n_gran = a.n_cb * a.m;
+    const uint64_t n_steps = (a.n_gran + 63) / 64;
+    // long runs amortise the replayed step; short batches still need wavefronts for 256 CUs
+    uint64_t spr = n_steps;
+    while (spr > 16 && n_streams * ((n_steps + spr - 1) / spr) < 8192) spr = (spr + 1) / 2;
+    a.steps_per_run = (uint32_t)spr;
+    a.runs_per_stream = (uint32_t)((n_steps + spr - 1) / spr);
+    a.n_tasks = n_streams * a.runs_per_stream;
+    a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
+    a.divisor = plan.divisor; a.threshold = plan.threshold;
+    const uint64_t grid64 = (a.n_tasks + 3) / 4;
+    if (grid64 > 0x7fffffffull || n_steps > 0xffffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
+    const unsigned grid = (unsigned)grid64;
+    if (plan.last_bin == 0) bd_gr_launch<0>(nyq, a, grid, st);
+    else if (plan.last_bin == 1) bd_gr_launch<1>(nyq, a, grid, st);
+    else bd_gr_launch<2>(nyq, a, grid, st);
+    bd_set_last_kernel("bd_spectrum_granule_kernel");
+    return bd_check_hip(hipGetLastError(), "launch bd_spectrum_granule_kernel");
+}

@@ -79,11 +79,40 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 64, 317, 529, 700, 1500, 2048, 3000])
+@pytest.mark.parametrize("L", [1, 7, 317, 529, 700, 1500, 3000, 4160, 8192])
 def test_spectrum_generic_callback_lengths(bd, oracle, L):
     x = _synth(bd, 2, 40000, first=3)
     _compare(bd, oracle, "Spectrum", SR, x, L)
     assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+
+
+@pytest.mark.parametrize("L", [64, 128, 192, 256, 448, 960, 1536, 2048, 3008, 4096])
+def test_spectrum_granule_callback_lengths(bd, oracle, L):
+    """Multiples of 64 other than 512 / 1024: the granule kernel; short streams, partial steps,
+    a stream long enough to be split into runs, and the generic kernel on the same data."""
+    for n, streams in ((40000, 3), (4096 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4096 * 40 + 5, 1)):
+        x = _synth(bd, streams, n, first=3)
+        res, ref_v, _, _ = _compare(bd, oracle, "Spectrum", SR, x, L)
+        assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
+    # the unpinned choices and other sampling rates take the same path
+    x = _synth(bd, 2, 50000, first=9, sr=22050)
+    _compare(bd, oracle, "Spectrum", 22050, x, L)
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2)):
+        _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+
+
+def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
+    import torch
+    x = torch.from_numpy(np.ascontiguousarray(np.pad(_synth(bd, 4, 4096 * 9 + 100, first=1), ((0, 0), (0, 28))))).cuda()
+    n = 4096 * 9 + 100
+    for L in (256, 2048, 704):
+        v1, f1 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
+        monkeypatch.setenv("BD_SPEC_NO_GRANULE", "1")
+        v2, f2 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
+        assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+        monkeypatch.delenv("BD_SPEC_NO_GRANULE")
+        assert torch.equal(f1, f2)
+        assert torch.isclose(v1, v2, rtol=1e-5, atol=1.0).all()
 
 
 @pytest.mark.parametrize("sr", [8000, 16000, 22050, 48000, 96000, 192000])
