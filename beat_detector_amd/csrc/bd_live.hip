@@ -362,6 +362,7 @@ struct bd_live {
     int            device = 0;
     uint32_t       n_streams = 0, max_len = 0, depth = 0;
     hipStream_t    stream = nullptr;
+    hipStream_t    cap_stream = nullptr; // graph capture only
     int16_t       *d_ring = nullptr;
     bd_live_state *d_state = nullptr;
     std::vector<bd_live_slot> slots;
@@ -430,6 +431,7 @@ extern "C" void bd_live_destroy(bd_live *L)
     if (L->d_ring) (void)hipFree(L->d_ring);
     if (L->d_state) (void)hipFree(L->d_state);
     if (L->stream) (void)hipStreamDestroy(L->stream);
+    if (L->cap_stream) (void)hipStreamDestroy(L->cap_stream);
     if (prev >= 0 && prev != L->device) (void)hipSetDevice(prev);
     delete L;
 }
@@ -438,6 +440,7 @@ static int bd_live_init(bd_live *L)
 {
     const size_t M = L->n_streams, cap = (size_t)L->max_len;
     BD_HIP(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+    BD_HIP(hipStreamCreateWithFlags(&L->cap_stream, hipStreamNonBlocking));
     BD_HIP(hipMalloc((void **)&L->d_ring, M * BD_RING_LEN * sizeof(int16_t)));
     BD_HIP(hipMalloc((void **)&L->d_state, M * sizeof(bd_live_state)));
     BD_HIP(hipMemsetAsync(L->d_ring, 0, M * BD_RING_LEN * sizeof(int16_t), L->stream)); // spectrum.rs:50-51
@@ -499,18 +502,20 @@ extern "C" int bd_live_set_on_beat(bd_live *L, bd_live_on_beat_fn cb, void *user
     return BD_OK;
 }
 
-// builds (captures) the graph of one tick for this slot, callback length and format
+// builds (captures) the graph of one tick for this slot, callback length and format.
+// Captured on a stream of its own: the dispatcher thread may be waiting on an event of the
+// working stream at the same moment, which a capture in progress on that stream does not survive.
 static int bd_live_build_graph(bd_live *L, bd_live_slot &s, uint32_t n, int format, hipGraphExec_t *out)
 {
     const size_t M = L->n_streams;
     const size_t elem = format == BD_FMT_F32 ? 4 : 2;
     hipGraph_t graph = nullptr;
-    BD_HIP(hipStreamBeginCapture(L->stream, hipStreamCaptureModeRelaxed));
-    hipError_t e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->stream);
+    BD_HIP(hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeRelaxed));
+    hipError_t e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->cap_stream);
     const int16_t *in16 = (const int16_t *)s.d_raw;
     if (e == hipSuccess && format != BD_FMT_I16) {
         const uint64_t total = (uint64_t)M * n;
-        hipLaunchKernelGGL(bd_live_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L->stream,
+        hipLaunchKernelGGL(bd_live_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L->cap_stream,
                            (const void *)s.d_raw, s.d_i16, total, format);
         in16 = s.d_i16;
     }
@@ -518,10 +523,10 @@ static int bd_live_build_graph(bd_live *L, bd_live_slot &s, uint32_t n, int form
         bd_live_args a;
         a.in = in16; a.in_stride = n; a.n = n;
         a.ring = L->d_ring; a.state = L->d_state; a.result = s.d_res; a.plan = L->plan;
-        hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->stream, a);
-        e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->stream);
+        hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->cap_stream, a);
+        e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->cap_stream);
     }
-    hipError_t e2 = hipStreamEndCapture(L->stream, &graph);
+    hipError_t e2 = hipStreamEndCapture(L->cap_stream, &graph);
     if (e != hipSuccess || e2 != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
         return bd_check_hip(e != hipSuccess ? e : e2, "capture live tick graph");

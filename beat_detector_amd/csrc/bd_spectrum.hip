@@ -276,37 +276,58 @@ __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generi
     const uint64_t s = t / a.n_cb, j = t - s * a.n_cb;
     const int16_t *sp = a.samples + s * a.stride;
     const int64_t end = (int64_t)(j + 1) * a.callback_len;
-    // ring = samples [end-1024, end), zeros before the stream starts (spectrum.rs:50-51)
+    // ring = samples [end-1024, end), zeros before the stream starts (spectrum.rs:50-51);
+    // lane l holds the 16 consecutive ring positions 16 l + i: two 16-byte loads at an address
+    // that is only 2-byte aligned (global memory allows it), 2 KB contiguous per wavefront
     float x[16];
+    const int64_t start = end - BD_RING_LEN + 16 * lane;
+    if (end >= BD_RING_LEN) {
+        typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+        const u32x4_a2 *p = reinterpret_cast<const u32x4_a2 *>(sp + start);
+        const bd_u32x4 lo = p[0], hi = p[1];
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int64_t idx = end - BD_RING_LEN + lane + 64 * i;
-        x[i] = idx >= 0 ? (float)sp[idx] : 0.f;
+        for (int q = 0; q < 8; q++) {
+            x[2 * q] = (float)(short)(w[q] & 0xffff);
+            x[2 * q + 1] = (float)(short)(w[q] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = start + i >= 0 ? (float)sp[start + i] : 0.f;
     }
-    // amplitude gate over the callback's own samples (spectrum.rs:77)
+    // amplitude gate over the callback's own samples (spectrum.rs:77): the tail of the ring,
+    // plus whatever of a longer callback lies before the ring
     float amax = 0.f;
-    for (int64_t idx = end - a.callback_len + lane; idx < end; idx += 64)
+    const int own_from = BD_RING_LEN - (int)(a.callback_len < BD_RING_LEN ? a.callback_len : BD_RING_LEN);
+#pragma unroll
+    for (int i = 0; i < 16; i++) amax = fmaxf(amax, (16 * lane + i >= own_from) ? fabsf(x[i]) : 0.f);
+    for (int64_t idx = end - a.callback_len + lane; idx < end - BD_RING_LEN; idx += 64)
         amax = fmaxf(amax, fabsf((float)sp[idx]));
     amax = fminf(bd_wave_max(amax), 32767.f);
     float best = 0.f;
     bool first = true;
     for (int k = a.first_bin; k <= a.last_bin; k++) {
+        // W^{k (16 l + i)} = W^{16 k l} W^{k i}: sixteen table values shared by the wavefront
+        // (scalar loads), one complex multiply per lane
         float re = 0.f, im = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const int m = (k * (lane + 64 * i)) & (BD_RING_LEN - 1);
+            const int m = (k * i) & (BD_RING_LEN - 1);
             re = __builtin_fmaf(x[i], bd_cos1024[m], re);
             im = __builtin_fmaf(x[i], bd_sin1024[m], im);
         }
-        re = bd_wave_sum(re);
-        im = bd_wave_sum(im);
+        const int ml = (k * 16 * lane) & (BD_RING_LEN - 1);
+        const float lc = bd_cos1024[ml], ls = bd_sin1024[ml];
+        float pr = re * lc - im * ls, pi = re * ls + im * lc;
+        pr = bd_wave_sum(pr);
+        pi = bd_wave_sum(pi);
         if (k == 0 && a.nyq) {
             float ny = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; i++) ny += (lane & 1) ? -x[i] : x[i];
-            im = bd_wave_sum(ny);
+            for (int i = 0; i < 16; i++) ny += (i & 1) ? -x[i] : x[i];
+            pi = bd_wave_sum(ny);
         }
-        const float mag = sqrtf(re * re + im * im);
+        const float mag = sqrtf(pr * pr + pi * pi);
         best = first ? mag : fmaxf(best, mag);
         first = false;
     }
