@@ -142,21 +142,57 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
             }
         }
     } else {
-        // element-wise staging: lane = sample inside the chunk, loop over rows
-        int16_t *tile16 = reinterpret_cast<int16_t *>(tile);
-        const int row_i16 = BD_LPF_ROW_U4 * 8;
+        // Rows that are only 2-byte aligned (callback length not a multiple of 8, odd strides):
+        // the same staging with 16-byte loads at unaligned addresses (global memory allows
+        // them); the piece that straddles the end of a window is gathered sample by sample so
+        // that nothing past the window -- possibly past the buffer -- is touched.
+        typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+        const int lrow = lane / PIECES, piece = lane % PIECES;
+        uint4 stage[PIECES];
+        auto load_chunk = [&](uint32_t ch) {
+            const uint32_t first = ch * BD_LPF_CHUNK + piece * 8; // sample offset inside the window
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) {
+                const uint32_t row = ROWS_PER_LOAD * i + lrow;
+                const int16_t *src = gp + (uint64_t)row * L + first;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < rows && first + 8 <= L) {
+                    const bd_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a2 *>(src));
+                    v = make_uint4(t.x, t.y, t.z, t.w);
+                } else if (row < rows && first < L) {
+                    unsigned w[4] = {0, 0, 0, 0};
+                    for (uint32_t e = 0; e < L - first; e++) w[e >> 1] |= (unsigned)(uint16_t)src[e] << (16 * (e & 1));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                stage[i] = v;
+            }
+        };
+        load_chunk(0);
         for (uint32_t ch = 0; ch < n_chunks; ch++) {
-            const uint32_t off = ch * BD_LPF_CHUNK + lane;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t row = 0; row < rows; row++)
-                tile16[row * row_i16 + lane] = off < L ? gp[(uint64_t)row * L + off] : (int16_t)0;
+#pragma unroll
+            for (int i = 0; i < PIECES; i++)
+                tile[(ROWS_PER_LOAD * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
+            if (ch + 1 < n_chunks) load_chunk(ch + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint32_t left = L - ch * BD_LPF_CHUNK;
             const int cnt = left >= (uint32_t)BD_LPF_CHUNK ? BD_LPF_CHUNK : (int)left;
-            for (int i = 0; i < cnt; i++)
-                bd_lpf_step((float)tile16[lane * row_i16 + i], alpha, y, ymax, xmax);
+            for (int p = 0; p < cnt / 8; p++) {
+                const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
+            if (cnt & 7) {
+                const int16_t *t16 = reinterpret_cast<const int16_t *>(tile + lane * BD_LPF_ROW_U4 + cnt / 8);
+                for (int e = 0; e < (cnt & 7); e++) bd_lpf_step((float)t16[e], alpha, y, ymax, xmax);
+            }
         }
     }
     bd_lpf_finish(a, s, j0, (unsigned)rows, lane, xmax, ymax);
