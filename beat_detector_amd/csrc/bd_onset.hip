@@ -9,20 +9,23 @@
 //     (E = 8 for N = 1024, E = 16 for N = 2048);
 //   * radix-2 decimation-in-time data flow in three register phases
 //     (4+4+2 stages for E = 16, 3+3+3 for E = 8) with two exchanges through a
-//     padded, bank-conflict-free LDS tile; the bit-reversal is folded into the
-//     global loads (lane L, slot q loads complex point rev(q) * 64 + rev6(L): every
-//     load instruction still covers 256 contiguous bytes), and because hop = N/2
-//     the raw points of a frame's second half are kept in registers for the next
-//     frame, so each sample is read from memory once;
-//   * twiddles of the first phase are compile-time constants, the others come
-//     from a padded table in LDS;
+//     padded LDS tile; the bit-reversal is folded into the global loads (lane L,
+//     slot q loads complex point rev(q) * 64 + rev6(L): every load instruction
+//     still covers 256 contiguous bytes), and because hop = N/2 the raw points of
+//     a frame's second half are kept in registers for the next frame, so each
+//     sample is read from memory once;
+//   * twiddles of the first phase are compile-time constants, those of the later
+//     phases and of the post-processing are prepared per lane in registers; the
+//     window comes from a table in LDS;
+//   * complex arithmetic on packed f32 instructions (a complex multiply is two, a
+//     butterfly four);
 //   * real-input post-processing pairs Z[k] with Z[M-k] through LDS, magnitudes
 //     stay in registers for the next frame's flux; sums over bins are per-lane
-//     partial sums + a xor butterfly.
+//     partial sums + a butterfly on the DPP network.
 // Every f32 operation is ordered exactly as in the CPU definition of the
 // analysis, so spectra, flux and band energy are reproduced bit for bit.
-// This kernel is bound by VALU / LDS throughput, not by HBM (about 60 VALU
-// operations per sample).
+// This kernel is bound by VALU issue, not by HBM (about 740 VALU instructions per
+// 2048-point frame and wavefront).
 #include "bd_internal.h"
 #include "bd_ext_tables.inc"
 
