@@ -31,11 +31,22 @@ struct bd_bq_args {
     float         *values;
     uint8_t       *flags;
     uint64_t       stride, out_stride, n_streams, n_windows, n_used;
+    uint32_t       misaligned;       // rows are not 16-byte aligned: loads at 2-byte-aligned addresses
     uint32_t       lanes_per_window; // window_len / 64
     uint32_t       min_amp;
     float          ratio;
     bd_biquad_design d;
 };
+
+// 16 bytes of samples; rows that are not 16-byte aligned are read at their 2-byte-aligned
+// addresses (global memory allows it, at a lower rate)
+__device__ __forceinline__ uint4 bd_bq_load16(const int16_t *p, bool misaligned)
+{
+    if (!misaligned) return bd_load_stream16(p);
+    typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+    const bd_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a2 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
 
 __device__ __forceinline__ void bd_bq_sync()
 {
@@ -98,18 +109,19 @@ __global__ __launch_bounds__(256, BD_BQ_WAVES) void bd_biquad_env_kernel(bd_bq_a
     // lies inside the analysed range loads from one base address; in the last, partial step
     // units past the range are replaced by the last valid one (their chunks are never
     // reported and cannot influence earlier ones).
+    const bool mis = a.misaligned != 0;
     uint4 ld[8];
     auto load_step = [&](uint64_t st) {
         if ((st + 1) * 4096 <= a.n_used) {
             const int16_t *base = sp + st * 4096 + lane * 8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) ld[j] = bd_load_stream16(base + j * 512);
+            for (int j = 0; j < 8; j++) ld[j] = bd_bq_load16(base + j * 512, mis);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 uint64_t unit = st * 512 + (uint64_t)(j * 64 + lane);
                 unit = unit < last_unit ? unit : last_unit;
-                ld[j] = bd_load_stream16(sp + unit * 8);
+                ld[j] = bd_bq_load16(sp + unit * 8, mis);
             }
         }
     };
@@ -283,12 +295,13 @@ extern "C" int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params
     const uint64_t n_win = n_samples / w;
     if (n_win == 0 || n_streams == 0) return BD_OK;
     if (!samples || !flags || stream_stride < n_samples) { bd_set_error("biquad envelope: bad buffers"); return BD_ERR_INVALID_ARG; }
-    if (((uintptr_t)samples % 16) || (stream_stride % 8)) { bd_set_error("biquad envelope: rows must be 16-byte aligned"); return BD_ERR_UNSUPPORTED; }
+    if ((uintptr_t)samples % 2) { bd_set_error("biquad envelope: samples must be 2-byte aligned"); return BD_ERR_INVALID_ARG; }
     if (out_stride == 0) out_stride = n_win;
     if (out_stride < n_win) { bd_set_error("out_stride < windows per stream"); return BD_ERR_INVALID_ARG; }
     a.samples = samples; a.values = values; a.flags = flags;
     a.stride = stream_stride; a.out_stride = out_stride; a.n_streams = n_streams;
     a.n_windows = n_win; a.n_used = n_win * w;
+    a.misaligned = (((uintptr_t)samples % 16) || (stream_stride % 8)) ? 1u : 0u;
     a.lanes_per_window = w / 64; a.min_amp = p.min_amplitude; a.ratio = p.ratio;
     const uint64_t grid64 = (n_streams + 3) / 4;
     if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }

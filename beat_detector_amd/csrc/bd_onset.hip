@@ -287,7 +287,9 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
     // raw points (two i16 per dword) of the current frame
     unsigned raw[E];
     const uint64_t f_first = f0 > 0 ? f0 - 1 : 0; // one frame of warm-up gives the flux its predecessor
-    const unsigned *fp = reinterpret_cast<const unsigned *>(sp + f_first * (uint64_t)M) + r6;
+    // rows need no alignment beyond that of a sample: dword loads at 2-byte-aligned addresses
+    typedef unsigned bd_u32_a2 __attribute__((aligned(2)));
+    const bd_u32_a2 *fp = reinterpret_cast<const bd_u32_a2 *>(sp + f_first * (uint64_t)M) + r6;
 #pragma unroll
     for (int q = 0; q < E; q++) raw[q] = __builtin_nontemporal_load(fp + bd_rev_bits(q, LGE) * 64);
 
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         }
         // next frame: its first half is this frame's second half (odd slots -> even slots)
         if (f + 1 < f_end) {
-            const unsigned *np = reinterpret_cast<const unsigned *>(sp + (f + 1) * (uint64_t)M) + r6;
+            const bd_u32_a2 *np = reinterpret_cast<const bd_u32_a2 *>(sp + (f + 1) * (uint64_t)M) + r6;
 #pragma unroll
             for (int q = 0; q < E; q += 2) {
                 raw[q] = raw[q + 1];
@@ -499,7 +501,7 @@ extern "C" int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, c
     const uint64_t n_frames = bd_onset_frames(n_samples, p->fft_len, p->hop);
     if (n_frames == 0 || n_streams == 0) return BD_OK;
     if (!samples || stream_stride < n_samples) { bd_set_error("bd_onset_stft: bad sample buffer"); return BD_ERR_INVALID_ARG; }
-    if (((uintptr_t)samples % 16) || (stream_stride % 8)) { bd_set_error("bd_onset_stft: rows must be 16-byte aligned"); return BD_ERR_UNSUPPORTED; }
+    if ((uintptr_t)samples % 2) { bd_set_error("bd_onset_stft: samples must be 2-byte aligned"); return BD_ERR_INVALID_ARG; }
     if (out_stride == 0) out_stride = n_frames;
     if (out_stride < n_frames) { bd_set_error("out_stride < frames per stream"); return BD_ERR_INVALID_ARG; }
     bd_onset_args a;

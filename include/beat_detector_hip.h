@@ -266,7 +266,7 @@ void bd_onset_default_params(bd_onset_params *p);
 uint64_t bd_onset_frames(uint64_t n_samples, uint32_t fft_len, uint32_t hop);
 /* flux[s * out_stride + j], band_energy[...] for every stream s and frame j
  * (either output may be NULL; out_stride 0 = frames per stream).  Rows of
- * `samples` must start on 16-byte boundaries. */
+ * `samples` may start anywhere; 128-byte aligned rows read fastest. */
 int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, const int16_t *samples,
                   uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,
                   float *flux, float *band_energy, uint64_t out_stride, void *hip_stream);
@@ -311,7 +311,7 @@ void bd_biquad_default_params(bd_biquad_params *p);
 int bd_biquad_design_lowpass(uint32_t sampling_rate, uint32_t cutoff_hz, float q_factor, bd_biquad_design *d);
 /* values[s * out_stride + w] = max |y| over window w (may be NULL), flags[...] = decision.
  * params NULL = defaults; design NULL = designed from params and sampling_rate.
- * Device pointers, enqueue only; rows of `samples` must start on 16-byte boundaries.
+ * Device pointers, enqueue only; rows of `samples` may start anywhere (16-byte aligned rows read fastest).
  * One wavefront per stream: the launch fills the GPU from about 2,000 streams up. */
 int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params *params, const bd_biquad_design *design,
                        const int16_t *samples, uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,

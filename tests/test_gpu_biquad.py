@@ -105,3 +105,21 @@ def test_beats_from_the_envelope(bd, oracle_ext, oracle):
         assert count[s] == len(beats) > 0
         got = list(zip(idx[s, :count[s]].cpu().tolist(), ms[s, :count[s]].cpu().tolist()))
         assert got == beats
+
+
+def test_rows_that_are_only_2_byte_aligned(bd, oracle_ext):
+    """Odd strides and an odd base offset: same results through the unaligned loads."""
+    import torch
+    n = 4096 * 3 + 1024 + 9
+    rows = _rows(5, n, seed=21)
+    stride = n + 3                                   # odd: rows start on odd sample offsets
+    flat = torch.zeros(1 + 5 * stride, dtype=torch.int16, device="cuda")
+    view = flat[1:].view(5, stride)                  # base 2 bytes off a 16-byte boundary
+    for i, r in enumerate(rows):
+        view[i, :n] = torch.from_numpy(r).cuda()
+    assert view.data_ptr() % 16 == 2
+    values, flags = bd.biquad_envelope(SR, view, n_samples=n)
+    for s in range(5):
+        want_v, want_f = oracle_ext.biquad_envelope(rows[s], SR)
+        assert np.array_equal(values[s].cpu().numpy().view(np.uint32), want_v.view(np.uint32)), s
+        assert np.array_equal(flags[s].cpu().numpy(), want_f), s

@@ -116,3 +116,24 @@ def test_large_batch_is_consistent(bd, oracle_ext):
         assert np.array_equal(res.band_energy[s].cpu().numpy().view(np.uint32), want_band.view(np.uint32))
         _, frame, ms = oracle_ext.onset_pick(want_flux, SR)
         assert res.onsets(s) == list(zip(frame.tolist(), ms.tolist()))
+
+
+def test_rows_that_are_only_2_byte_aligned(bd, oracle_ext):
+    """Odd strides and an odd base offset: same results (dword loads at 2-byte-aligned addresses)."""
+    import torch
+    n = 2048 * 9 + 31
+    rows = _streams(5, n, seed=4)
+    stride = n + 1
+    flat = torch.zeros(1 + 5 * stride, dtype=torch.int16, device="cuda")
+    view = flat[1:].view(5, stride)
+    for i, r in enumerate(rows):
+        view[i, :n] = torch.from_numpy(r).cuda()
+    assert view.data_ptr() % 4 == 2
+    for fft_len in (1024, 2048):
+        res = bd.onset_batch(SR, view, n_samples=n, params=bd.OnsetParams.default(fft_len=fft_len))
+        op = oracle_ext.default_params(fft_len=fft_len)
+        for s in range(5):
+            flux, band = oracle_ext.onset_stft(rows[s], SR, op)
+            assert np.array_equal(res.flux[s].cpu().numpy().view(np.uint32), flux.view(np.uint32)), s
+            _, frame, ms = oracle_ext.onset_pick(flux, SR, op)
+            assert res.onsets(s) == list(zip(frame.tolist(), ms.tolist()))
