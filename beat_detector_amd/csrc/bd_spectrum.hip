@@ -399,7 +399,8 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");
     }
     // other multiples of 64 up to 4096: the granule kernel (BD_SPEC_NO_GRANULE=1 forces the generic one)
-    if (aligned && fast_bins && callback_len % 64 == 0 && callback_len <= 4096 && !getenv("BD_SPEC_NO_GRANULE"))
+    // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)
+    if (fast_bins && callback_len % 64 == 0 && callback_len <= 4096 && !getenv("BD_SPEC_NO_GRANULE"))
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
     bd_spec_generic_args a;

@@ -34,10 +34,19 @@ struct bd_gr_args {
     uint64_t       stride, out_stride, n_cb, n_tasks;
     uint64_t       n_gran;          // granules that belong to callbacks = n_cb * m
     uint32_t       m;               // granules per callback (1 .. 64)
+    uint32_t       misaligned;      // rows are not 16-byte aligned: loads at 2-byte-aligned addresses
     uint32_t       steps_per_run, runs_per_stream;
     uint32_t       min_amp, include_dc;
     float          divisor, threshold;
 };
+
+__device__ __forceinline__ uint4 bd_gr_load16(const int16_t *p, bool misaligned)
+{
+    if (!misaligned) return bd_load_stream16(p);
+    typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+    const bd_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a2 *>(p));
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
 
 __device__ __forceinline__ void bd_gr_sync()
 {
@@ -91,18 +100,19 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
     const int lg = 31 - __builtin_clz(m);
     const int tail = (int)m - (1 << lg);
 
+    const bool mis = a.misaligned != 0;
     uint4 ld[8];
     auto load_step = [&](uint64_t st) {
         if ((st + 1) * 64 <= a.n_gran) {
             const int16_t *base = sp + st * 4096 + lane * 8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) ld[j] = bd_load_stream16(base + j * 512);
+            for (int j = 0; j < 8; j++) ld[j] = bd_gr_load16(base + j * 512, mis);
         } else { // units past the analysed range are replaced by the last valid one (never reported)
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 uint64_t unit = st * 512 + (uint64_t)(j * 64 + lane);
                 unit = unit < last_unit ? unit : last_unit;
-                ld[j] = bd_load_stream16(sp + unit * 8);
+                ld[j] = bd_gr_load16(sp + unit * 8, mis);
             }
         }
     };
@@ -241,8 +251,7 @@ static void bd_gr_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStream
 }
 
 // Returns BD_OK after enqueueing, or a negative status; the caller has checked that
-// callback_len is a multiple of 64 not above 4096, rows are 16-byte aligned and the kept
-// bins are 0 .. last_bin <= 2.
+// callback_len is a multiple of 64 not above 4096 and the kept bins are 0 .. last_bin <= 2.
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
                                uint64_t out_stride, hipStream_t st)
@@ -252,6 +261,7 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     a.stride = stride; a.out_stride = out_stride;
     a.n_cb = n_samples / callback_len;
     a.m = callback_len / 64;
+    a.misaligned = (((uintptr_t)samples % 16) || (stride % 8)) ? 1u : 0u;
     a.n_gran = a.n_cb * a.m;
     const uint64_t n_steps = (a.n_gran + 63) / 64;
     // long runs amortise the replayed step; short batches still need wavefronts for 256 CUs

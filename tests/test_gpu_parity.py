@@ -349,6 +349,34 @@ def test_full_size_properties_spectrum(bd):
     assert int(full.beat_count.sum()) > 0
 
 
+def test_rows_that_are_only_2_byte_aligned(bd, oracle):
+    """Odd strides and an odd base offset: every strategy and callback length still matches."""
+    torch = _torch()
+    n = SR * 2 + 11
+    x = _synth(bd, 4, n, first=40)
+    stride = n + 3
+    flat = torch.zeros(1 + 4 * stride, dtype=torch.int16, device="cuda")
+    view = flat[1:].view(4, stride)
+    view[:, :n] = torch.from_numpy(x).cuda()
+    assert view.data_ptr() % 4 == 2
+    for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
+                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_generic_kernel"),
+                                 ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
+        kind = bd.StrategyKind[kind_name]
+        okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+        res = bd.analyze_batch(kind, SR, view, L, n_samples=n)
+        torch.cuda.synchronize()
+        assert bd.last_kernel_name() == kernel
+        ref_v, ref_c, ref_b = util.oracle_batch(oracle, okind, SR, x, L)
+        np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
+        for s in range(4):
+            assert res.beats(s) == ref_b[s]
+        if kind_name == "LPF":
+            np.testing.assert_array_equal(res.values.cpu().numpy(), ref_v)
+        else:
+            assert (np.abs(res.values.cpu().numpy() - ref_v) <= util.value_tolerance(ref_v, 32768, 3)).all()
+
+
 def test_tuning_knobs_do_not_change_results(bd, oracle, monkeypatch):
     """Every value of the experiment knobs selects code that must give the same answers."""
     x = _synth(bd, 4, SR * 10, first=60)
