@@ -66,6 +66,51 @@ extern "C" {
         n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8,
         beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, device: c_int,
     ) -> c_int;
+    pub fn bd_refractory(
+        sampling_rate: u32, params: *const bd_params, callback_len: u32, flags: *const u8, flags_stride: u64,
+        n_streams: u64, n_callbacks: u64, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32,
+        max_beats: u32, hip_stream: *mut c_void,
+    ) -> c_int;
+    // Extension analyses: no counterpart in the parent crate (device pointers, enqueue only).
+    pub fn bd_onset_default_params(p: *mut bd_onset_params);
+    pub fn bd_onset_frames(n_samples: u64, fft_len: u32, hop: u32) -> u64;
+    pub fn bd_onset_batch(
+        sampling_rate: u32, p: *const bd_onset_params, samples: *const i16, n_streams: u64, n_samples: u64,
+        stream_stride: u64, flux: *mut f32, band_energy: *mut f32, out_stride: u64, onset_count: *mut u32,
+        onset_frame: *mut u32, onset_ms: *mut u32, max_onsets: u32, hip_stream: *mut c_void,
+    ) -> c_int;
+    pub fn bd_biquad_default_params(p: *mut bd_biquad_params);
+    pub fn bd_biquad_envelope(
+        sampling_rate: u32, params: *const bd_biquad_params, design: *const c_void, samples: *const i16,
+        n_streams: u64, n_samples: u64, stream_stride: u64, values: *mut f32, flags: *mut u8, out_stride: u64,
+        hip_stream: *mut c_void,
+    ) -> c_int;
+}
+
+/// `bd_onset_params` of the C header.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct bd_onset_params {
+    pub fft_len: u32,
+    pub hop: u32,
+    pub window: u32,
+    pub band_max_hz: f32,
+    pub mean_frames: u32,
+    pub max_frames: u32,
+    pub delta: f32,
+    pub lambda: f32,
+    pub min_gap_ms: u32,
+}
+
+/// `bd_biquad_params` of the C header.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct bd_biquad_params {
+    pub cutoff_hz: u32,
+    pub q_factor: f32,
+    pub window_len: u32,
+    pub ratio: f32,
+    pub min_amplitude: u32,
 }
 
 /// Message of the last failed call on this thread.
