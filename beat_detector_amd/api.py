@@ -176,6 +176,7 @@ def lib() -> C.CDLL:
         "bd_batch_callbacks": (u64, [u64, u32]),
         "bd_batch_max_beats": (u32, [u32, u32, pp, u64, u32]),
         "bd_analyze_batch": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_analyze_batch_ragged": (i32, [i32, u32, pp, vp, u64, vp, u64, u64, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
         "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp]),
         "bd_analyze_batch_host": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, i32]),
         "bd_analyze_batch_multi": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, C.POINTER(i32), i32]),
@@ -215,7 +216,7 @@ EXPORTED_SYMBOLS = (
     "bd_default_params bd_strerror bd_last_error bd_device_count bd_kind_count bd_kind_name "
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
-    "bd_batch_max_beats bd_analyze_batch bd_batch_candidates bd_analyze_batch_host "
+    "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
@@ -458,6 +459,35 @@ def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len:
                                       callback_len, _dev_ptr(out.values), out.flags.data_ptr(),
                                       _row_stride(out.flags, out.values), out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
                                       out.beat_idx.shape[1], _stream_ptr(stream)))
+    return out
+
+
+def analyze_batch_ragged(kind: StrategyKind, sampling_rate: int, samples, lengths, callback_len: int,
+                         params: Optional[Params] = None, max_beats: Optional[int] = None, want_values: bool = True,
+                         stream=None) -> BatchResult:
+    """bd_analyze_batch_ragged: row s of the CUDA int16 tensor holds lengths[s] samples (CUDA int64 tensor)."""
+    _require_cuda(samples, torch.int16, "samples")
+    _require_cuda(lengths, torch.int64, "lengths")
+    n_streams, stride = samples.shape
+    if lengths.shape != (n_streams,):
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "lengths must have one entry per stream")
+    n_cb = stride // callback_len if callback_len else 0
+    dev = samples.device
+    if max_beats is None:
+        max_beats = max(1, batch_max_beats(kind, sampling_rate, stride, callback_len, params)) if callback_len else 1
+    out = BatchResult(
+        _out_rows(n_streams, n_cb, torch.float32, dev) if want_values else None,
+        _out_rows(n_streams, n_cb, torch.uint8, dev),
+        torch.zeros((n_streams,), dtype=torch.int32, device=dev),
+        torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
+        torch.zeros((n_streams, max_beats), dtype=torch.int32, device=dev),
+    )
+    with torch.cuda.device(dev):
+        _check(lib().bd_analyze_batch_ragged(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams,
+                                             lengths.data_ptr(), stride, stride, callback_len, _dev_ptr(out.values),
+                                             out.flags.data_ptr(), _row_stride(out.flags, out.values),
+                                             out.beat_count.data_ptr(), out.beat_idx.data_ptr(),
+                                             out.beat_ms.data_ptr(), max_beats, _stream_ptr(stream)))
     return out
 
 

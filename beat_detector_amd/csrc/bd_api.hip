@@ -274,6 +274,34 @@ extern "C" int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_param
     return s;
 }
 
+extern "C" int bd_analyze_batch_ragged(int kind, uint32_t sampling_rate, const bd_params *params,
+                                       const int16_t *samples, uint64_t n_streams, const uint64_t *lengths,
+                                       uint64_t max_samples, uint64_t stream_stride, uint32_t callback_len,
+                                       float *values, uint8_t *flags, uint64_t out_stride,
+                                       uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                                       uint32_t max_beats, void *hip_stream)
+{
+    if (!lengths) { bd_set_error("bd_analyze_batch_ragged: lengths must not be NULL"); return BD_ERR_INVALID_ARG; }
+    bd_plan plan;
+    int s = bd_make_plan(kind, sampling_rate, params, &plan);
+    if (s != BD_OK) return s;
+    s = bd_check_batch_args(samples, max_samples, stream_stride, callback_len, flags);
+    if (s != BD_OK) return s;
+    if (!beat_count) { bd_set_error("beat_count must not be NULL"); return BD_ERR_INVALID_ARG; }
+    s = bd_resolve_out_stride(&out_stride, max_samples / callback_len);
+    if (s != BD_OK) return s;
+    hipStream_t st = (hipStream_t)hip_stream;
+    // every row is analysed to the common length: a callback depends on samples before its end
+    // only, so whatever follows a stream's own samples cannot reach its own callbacks
+    s = bd_candidates_impl(plan, samples, n_streams, max_samples, stream_stride, callback_len, values, flags, out_stride, st);
+    if (s != BD_OK) return s;
+    const char *k = bd_last_kernel;
+    s = bd_launch_refractory(plan, callback_len, flags, out_stride, n_streams, max_samples / callback_len,
+                             beat_count, beat_idx, beat_ms, max_beats, st, lengths);
+    bd_last_kernel = k;
+    return s;
+}
+
 // device buffers of one host-pointer call
 struct bd_host_job {
     int16_t *d_samples = nullptr; float *d_values = nullptr; uint8_t *d_flags = nullptr;

@@ -52,7 +52,7 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
 int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8_t *flags,
                          uint64_t flags_stride, uint64_t n_streams, uint64_t n_cb, uint32_t *beat_count,
                          uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
-                         hipStream_t st);
+                         hipStream_t st, const uint64_t *lengths = nullptr);
 
 // Rust `as` casts on the host
 static inline uint32_t bd_f32_as_u32(float x)

@@ -15,14 +15,20 @@
 #include "bd_internal.h"
 
 __global__ __launch_bounds__(256) void bd_refractory_kernel(
-    const uint8_t *flags, uint64_t flags_stride, uint64_t n_streams, uint64_t n_cb,
-    uint32_t step_ms, uint32_t half_ms, uint32_t gap_ms,
+    const uint8_t *flags, uint64_t flags_stride, uint64_t n_streams, uint64_t n_cb_max,
+    const uint64_t *lengths, uint32_t callback_len, uint32_t step_ms, uint32_t half_ms, uint32_t gap_ms,
     uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n_streams) return; // wave-uniform
     const uint8_t *f = flags + s * flags_stride;
+    // a stream shorter than the batch stops at its own last complete callback
+    uint64_t n_cb = n_cb_max;
+    if (lengths) {
+        const uint64_t own = lengths[s] / callback_len;
+        n_cb = own < n_cb_max ? own : n_cb_max;
+    }
     uint32_t last_beat = 0, count = 0;
     for (uint64_t base = 0; base < n_cb; base += 64) {
         const uint64_t j = base + lane;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(256) void bd_refractory_kernel(
 int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8_t *flags,
                          uint64_t flags_stride, uint64_t n_streams, uint64_t n_cb, uint32_t *beat_count,
                          uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
-                         hipStream_t st)
+                         hipStream_t st, const uint64_t *lengths)
 {
     if (n_streams == 0) return BD_OK;
     uint32_t step_ms, half_ms;
@@ -62,7 +68,7 @@ int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8
     const uint64_t grid64 = (n_streams + 3) / 4;
     if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(bd_refractory_kernel, dim3((unsigned)grid64), dim3(256), 0, st,
-                       flags, flags_stride, n_streams, n_cb, step_ms, half_ms, plan.gap_ms,
+                       flags, flags_stride, n_streams, n_cb, lengths, callback_len, step_ms, half_ms, plan.gap_ms,
                        beat_count, beat_idx, beat_ms, max_beats);
     return bd_check_hip(hipGetLastError(), "launch bd_refractory_kernel");
 }

@@ -136,6 +136,19 @@ int bd_analyze_batch(int kind, uint32_t sampling_rate, const bd_params *params,
                      uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                      uint32_t max_beats, void *hip_stream);
 
+/* Streams of different lengths in one batch (tracks of a library): row s holds
+ * lengths[s] <= max_samples samples (`lengths` is a device array of n_streams
+ * u64); the rest of the row may hold anything.  Stream s gets the beats of its
+ * own lengths[s] / callback_len callbacks, exactly as if analysed alone
+ * (src/lib.rs:276-292 drops a trailing partial window per file); values / flags
+ * entries past a stream's own callbacks are written but meaningless. */
+int bd_analyze_batch_ragged(int kind, uint32_t sampling_rate, const bd_params *params,
+                            const int16_t *samples, uint64_t n_streams, const uint64_t *lengths,
+                            uint64_t max_samples, uint64_t stream_stride, uint32_t callback_len,
+                            float *values, uint8_t *flags, uint64_t out_stride,
+                            uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                            uint32_t max_beats, void *hip_stream);
+
 /* First stage of bd_analyze_batch alone: per-callback value and decision
  * (amplitude gate + strategy decision, src/strategies/spectrum.rs:77-92 /
  * lpf.rs:60-75), without the refractory rule.  Same pointer rules. */

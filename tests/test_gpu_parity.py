@@ -377,6 +377,33 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
             assert (np.abs(res.values.cpu().numpy() - ref_v) <= util.value_tolerance(ref_v, 32768, 3)).all()
 
 
+@pytest.mark.parametrize("kind_name", ["Spectrum", "LPF"])
+def test_ragged_batch(bd, oracle, kind_name):
+    """Streams of different lengths in one batch (zero, shorter than a callback, exact multiples,
+    trailing partial callbacks; garbage after each stream's own samples): every stream as if alone."""
+    torch = _torch()
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    lens = [0, 100, 1024, 1025, SR * 3, SR * 3 + 511, 512 * 40, SR * 5 - 1]
+    nmax = max(lens)
+    x = _synth(bd, len(lens), nmax, first=11)
+    rng = np.random.default_rng(1)
+    host = x.copy()
+    for i, n in enumerate(lens):
+        host[i, n:] = rng.integers(-32768, 32768, nmax - n)      # what follows a stream must not matter
+    buf = torch.zeros((len(lens), (nmax + 63) & ~63), dtype=torch.int16, device="cuda")
+    buf[:, :nmax] = torch.from_numpy(host).cuda()
+    lengths = torch.tensor(lens, dtype=torch.int64, device="cuda")
+    for L in (512, 1024, 256, 441):
+        res = bd.analyze_batch_ragged(kind, SR, buf, lengths, L)
+        torch.cuda.synchronize()
+        for i, n in enumerate(lens):
+            v, c, beats = oracle.run_stream(okind, SR, x[i, :n], L, full=True) if n >= L else (np.zeros(0), np.zeros(0), [])
+            assert res.beats(i) == beats, (L, i)
+            assert int(res.beat_count[i]) == len(beats)
+            np.testing.assert_array_equal(res.flags[i, :len(c)].cpu().numpy(), c)
+
+
 def test_tuning_knobs_do_not_change_results(bd, oracle, monkeypatch):
     """Every value of the experiment knobs selects code that must give the same answers."""
     x = _synth(bd, 4, SR * 10, first=60)
