@@ -5,6 +5,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -302,13 +303,19 @@ extern "C" int bd_analyze_batch_ragged(int kind, uint32_t sampling_rate, const b
     return s;
 }
 
-// device buffers of one host-pointer call
-struct bd_host_job {
+// Host-pointer batches are processed in chunks of streams through two slots: while the GPU
+// copies and analyses one chunk, host threads pack the next one into pinned memory (rows
+// repacked to start on 128-byte boundaries).  Device and pinned memory stay bounded whatever
+// the batch size, and the copy runs at pinned-memory PCIe speed instead of pageable speed.
+struct bd_host_slot {
+    int16_t *h_in = nullptr;      // pinned staging
     int16_t *d_samples = nullptr; float *d_values = nullptr; uint8_t *d_flags = nullptr;
     uint32_t *d_count = nullptr, *d_idx = nullptr, *d_ms = nullptr;
     hipStream_t st = nullptr;
     void release()
     {
+        if (st) { (void)hipStreamSynchronize(st); }
+        if (h_in) (void)hipHostFree(h_in);
         if (d_samples) (void)hipFree(d_samples);
         if (d_values) (void)hipFree(d_values);
         if (d_flags) (void)hipFree(d_flags);
@@ -318,6 +325,30 @@ struct bd_host_job {
         if (st) (void)hipStreamDestroy(st);
     }
 };
+struct bd_host_job {
+    bd_host_slot slot[2];
+    void release() { slot[0].release(); slot[1].release(); }
+};
+
+#define BD_HOST_CHUNK_BYTES (256ull << 20)
+#define BD_HOST_PACK_THREADS 8
+
+static void bd_host_pack(int16_t *dst, uint64_t d_stride, const int16_t *src, uint64_t stride, uint64_t n_samples,
+                         uint64_t rows)
+{
+    const char *env = getenv("BD_HOST_THREADS"); // tuning knob
+    const unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : BD_HOST_PACK_THREADS;
+    const unsigned n_thr = rows >= 4 * want ? want : 1;
+    auto work = [=](unsigned t) {
+        for (uint64_t r = rows * t / n_thr; r < rows * (t + 1) / n_thr; r++)
+            memcpy(dst + r * d_stride, src + r * stride, n_samples * sizeof(int16_t));
+    };
+    if (n_thr == 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_thr; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+}
 
 static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const bd_params *params,
                        const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
@@ -325,38 +356,59 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
                        uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
 {
     const uint64_t n_cb = n_samples / callback_len;
+    if (n_cb == 0) { // no complete callback anywhere: nothing to copy or launch
+        memset(beat_count, 0, n_streams * sizeof(uint32_t));
+        return BD_OK;
+    }
     // input and output rows are repacked so that each starts on a 128-byte
     // boundary: the fast kernels apply and every load / store covers whole lines
     const uint64_t d_stride = (n_samples + 63) & ~63ull;
     const uint64_t o_stride = (n_cb + 127) & ~127ull;
-    const uint64_t n_out = n_streams * o_stride;
-    BD_HIP(hipStreamCreateWithFlags(&j.st, hipStreamNonBlocking));
-    BD_HIP(hipMalloc((void **)&j.d_samples, (n_streams * d_stride + 8) * sizeof(int16_t)));
-    if (n_out) {
-        BD_HIP(hipMalloc((void **)&j.d_flags, n_out));
-        if (values) BD_HIP(hipMalloc((void **)&j.d_values, n_out * sizeof(float)));
+    uint64_t chunk = BD_HOST_CHUNK_BYTES / (d_stride * sizeof(int16_t));
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_streams) chunk = n_streams;
+    const uint64_t n_chunks = (n_streams + chunk - 1) / chunk;
+    const int n_slots = n_chunks > 1 ? 2 : 1;
+    for (int i = 0; i < n_slots; i++) {
+        bd_host_slot &sl = j.slot[i];
+        BD_HIP(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        BD_HIP(hipHostMalloc((void **)&sl.h_in, chunk * d_stride * sizeof(int16_t), hipHostMallocDefault));
+        BD_HIP(hipMalloc((void **)&sl.d_samples, (chunk * d_stride + 8) * sizeof(int16_t)));
+        BD_HIP(hipMalloc((void **)&sl.d_flags, chunk * o_stride));
+        if (values) BD_HIP(hipMalloc((void **)&sl.d_values, chunk * o_stride * sizeof(float)));
+        BD_HIP(hipMalloc((void **)&sl.d_count, (chunk + 1) * sizeof(uint32_t)));
+        if (max_beats && beat_idx) BD_HIP(hipMalloc((void **)&sl.d_idx, chunk * max_beats * sizeof(uint32_t)));
+        if (max_beats && beat_ms) BD_HIP(hipMalloc((void **)&sl.d_ms, chunk * max_beats * sizeof(uint32_t)));
     }
-    BD_HIP(hipMalloc((void **)&j.d_count, (n_streams + 1) * sizeof(uint32_t)));
-    if (max_beats && beat_idx) BD_HIP(hipMalloc((void **)&j.d_idx, n_streams * max_beats * sizeof(uint32_t)));
-    if (max_beats && beat_ms) BD_HIP(hipMalloc((void **)&j.d_ms, n_streams * max_beats * sizeof(uint32_t)));
-    BD_HIP(hipMemcpy2DAsync(j.d_samples, d_stride * sizeof(int16_t), samples, stride * sizeof(int16_t),
-                            n_samples * sizeof(int16_t), n_streams, hipMemcpyHostToDevice, j.st));
-    if (n_out == 0) {
-        BD_HIP(hipMemsetAsync(j.d_count, 0, n_streams * sizeof(uint32_t), j.st));
-    } else {
-        int s = bd_analyze_batch(kind, sampling_rate, params, j.d_samples, n_streams, n_samples, d_stride,
-                                 callback_len, j.d_values, j.d_flags, o_stride, j.d_count, j.d_idx, j.d_ms,
-                                 max_beats, j.st);
+    // results of chunk c to the caller's (pageable) memory; such copies may hold the host until
+    // the chunk's kernels have finished, so they are issued after the next chunk has been
+    // packed and enqueued
+    auto drain = [&](uint64_t c) -> int {
+        bd_host_slot &sl = j.slot[c & 1];
+        const uint64_t s0 = c * chunk, rows = (s0 + chunk <= n_streams) ? chunk : n_streams - s0;
+        if (values) BD_HIP(hipMemcpy2DAsync(values + s0 * n_cb, n_cb * sizeof(float), sl.d_values, o_stride * sizeof(float),
+                                            n_cb * sizeof(float), rows, hipMemcpyDeviceToHost, sl.st));
+        if (flags) BD_HIP(hipMemcpy2DAsync(flags + s0 * n_cb, n_cb, sl.d_flags, o_stride, n_cb, rows,
+                                           hipMemcpyDeviceToHost, sl.st));
+        BD_HIP(hipMemcpyAsync(beat_count + s0, sl.d_count, rows * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.st));
+        if (sl.d_idx) BD_HIP(hipMemcpyAsync(beat_idx + s0 * max_beats, sl.d_idx, rows * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.st));
+        if (sl.d_ms) BD_HIP(hipMemcpyAsync(beat_ms + s0 * max_beats, sl.d_ms, rows * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, sl.st));
+        return BD_OK;
+    };
+    for (uint64_t c = 0; c < n_chunks; c++) {
+        bd_host_slot &sl = j.slot[c & 1];
+        const uint64_t s0 = c * chunk, rows = (s0 + chunk <= n_streams) ? chunk : n_streams - s0;
+        BD_HIP(hipStreamSynchronize(sl.st)); // the slot's previous chunk is complete, results included
+        bd_host_pack(sl.h_in, d_stride, samples + s0 * stride, stride, n_samples, rows);
+        BD_HIP(hipMemcpyAsync(sl.d_samples, sl.h_in, rows * d_stride * sizeof(int16_t), hipMemcpyHostToDevice, sl.st));
+        int s = bd_analyze_batch(kind, sampling_rate, params, sl.d_samples, rows, n_samples, d_stride,
+                                 callback_len, sl.d_values, sl.d_flags, o_stride, sl.d_count, sl.d_idx, sl.d_ms,
+                                 max_beats, sl.st);
         if (s != BD_OK) return s;
-        if (values) BD_HIP(hipMemcpy2DAsync(values, n_cb * sizeof(float), j.d_values, o_stride * sizeof(float),
-                                            n_cb * sizeof(float), n_streams, hipMemcpyDeviceToHost, j.st));
-        if (flags) BD_HIP(hipMemcpy2DAsync(flags, n_cb, j.d_flags, o_stride, n_cb, n_streams,
-                                           hipMemcpyDeviceToHost, j.st));
+        if (c > 0) { s = drain(c - 1); if (s != BD_OK) return s; }
     }
-    BD_HIP(hipMemcpyAsync(beat_count, j.d_count, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
-    if (j.d_idx) BD_HIP(hipMemcpyAsync(beat_idx, j.d_idx, n_streams * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
-    if (j.d_ms) BD_HIP(hipMemcpyAsync(beat_ms, j.d_ms, n_streams * max_beats * sizeof(uint32_t), hipMemcpyDeviceToHost, j.st));
-    BD_HIP(hipStreamSynchronize(j.st));
+    { int s = drain(n_chunks - 1); if (s != BD_OK) return s; }
+    for (int i = 0; i < n_slots; i++) BD_HIP(hipStreamSynchronize(j.slot[i].st));
     return BD_OK;
 }
 
