@@ -364,7 +364,9 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
     // boundary: the fast kernels apply and every load / store covers whole lines
     const uint64_t d_stride = (n_samples + 63) & ~63ull;
     const uint64_t o_stride = (n_cb + 127) & ~127ull;
-    uint64_t chunk = BD_HOST_CHUNK_BYTES / (d_stride * sizeof(int16_t));
+    const char *chunk_env = getenv("BD_HOST_CHUNK_BYTES"); // tests use small chunks to exercise the pipeline
+    const uint64_t chunk_bytes = chunk_env && atoll(chunk_env) > 0 ? (uint64_t)atoll(chunk_env) : BD_HOST_CHUNK_BYTES;
+    uint64_t chunk = chunk_bytes / (d_stride * sizeof(int16_t));
     if (chunk < 1) chunk = 1;
     if (chunk > n_streams) chunk = n_streams;
     const uint64_t n_chunks = (n_streams + chunk - 1) / chunk;

@@ -318,6 +318,20 @@ def test_host_pointer_entry_points(bd, oracle):
                 assert res.beats(s) == ref_b[s]
 
 
+def test_host_entry_in_many_chunks(bd, oracle, monkeypatch):
+    """The host-pointer entry with chunks of 3 streams (two slots reused many times), all outputs requested."""
+    n = SR * 2 + 100
+    x = np.zeros((20, n + 37), dtype=np.int16)
+    x[:, :n] = _synth(bd, 20, n, first=200)
+    monkeypatch.setenv("BD_HOST_CHUNK_BYTES", str(3 * ((n + 63) & ~63) * 2))
+    for kind, okind in ((bd.StrategyKind.Spectrum, oracle.KIND_SPECTRUM), (bd.StrategyKind.LPF, oracle.KIND_LPF)):
+        _, ref_c, ref_b = util.oracle_batch(oracle, okind, SR, x[:, :n], 512)
+        res = bd.analyze_batch_host(kind, SR, x[:, :n], 512)
+        np.testing.assert_array_equal(res.flags, ref_c)
+        for s in range(20):
+            assert res.beats(s) == ref_b[s]
+
+
 def test_full_size_properties_spectrum(bd):
     """At a size the oracle cannot finish: size-independent properties.
     (a) a stream's results do not depend on which batch it is analysed in;
