@@ -137,32 +137,53 @@ extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, voi
 
 // ---- read-bandwidth probe -----------------------------------------------------
 // The ceiling the sample-streaming kernels are measured against: the same 16-byte
-// non-temporal loads (4 per lane in flight, 256 contiguous bytes per 16 lanes), no
-// arithmetic beyond an xor, one dword written per wavefront.
-__global__ __launch_bounds__(256) void bd_probe_read_kernel(const uint4 *src, uint64_t n_units, uint32_t *sink)
+// non-temporal loads (256 contiguous bytes per 16 lanes), no arithmetic beyond an
+// xor, one dword written per wavefront.  DEPTH loads per lane are in flight; with
+// `contiguous` every wavefront walks its own contiguous share of the buffer (as
+// the analysis kernels walk their runs), otherwise the wavefronts sweep the
+// buffer side by side.
+template <int DEPTH>
+__global__ __launch_bounds__(256) void bd_probe_read_kernel(const uint4 *src, uint64_t n_units, uint32_t *sink, int contiguous)
 {
     const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * 256) >> 6;
     const int lane = threadIdx.x & 63;
+    constexpr uint64_t STEP = 64 * DEPTH; // units per wavefront step
     uint32_t acc = 0;
-    // a wavefront reads 4 KB (256 units) per step, steps strided by the number of wavefronts
-    for (uint64_t base = wave * 256; base + 256 <= n_units; base += n_waves * 256) {
-        uint4 v[4];
+    uint64_t base, end, stride;
+    if (contiguous) {
+        const uint64_t share = (n_units / n_waves) / STEP * STEP;
+        base = wave * share; end = base + share; stride = STEP;
+    } else {
+        base = wave * STEP; end = n_units / STEP * STEP; stride = n_waves * STEP;
+    }
+    for (; base + STEP <= end; base += stride) {
+        uint4 v[DEPTH];
 #pragma unroll
-        for (int c = 0; c < 4; c++) v[c] = bd_load_stream16(src + base + 64 * c + lane);
+        for (int c = 0; c < DEPTH; c++) v[c] = bd_load_stream16(src + base + 64 * c + lane);
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc ^= v[c].x ^ v[c].y ^ v[c].z ^ v[c].w;
+        for (int c = 0; c < DEPTH; c++) acc ^= v[c].x ^ v[c].y ^ v[c].z ^ v[c].w;
     }
     acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)bd_row_sum((int)acc));
     if (lane == 0 && sink) sink[wave] = acc;
 }
 
-extern "C" int bd_probe_read(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu, void *hip_stream)
+extern "C" int bd_probe_read_ex(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu,
+                                uint32_t depth, uint32_t contiguous, void *hip_stream)
 {
     if (!src || ((uintptr_t)src % 16)) { bd_set_error("bd_probe_read: src must be a 16-byte aligned device pointer"); return BD_ERR_INVALID_ARG; }
     if (waves_per_cu == 0 || waves_per_cu > 32) waves_per_cu = 16;
-    const unsigned grid = 256u * waves_per_cu / 4u; // 256 CUs, 4 wavefronts per block
-    hipLaunchKernelGGL(bd_probe_read_kernel, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream,
-                       reinterpret_cast<const uint4 *>(src), bytes / 16, sink);
+    const unsigned grid = (256u * waves_per_cu + 3) / 4u; // 256 CUs, 4 wavefronts per block
+    const uint4 *p = reinterpret_cast<const uint4 *>(src);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (depth == 8) hipLaunchKernelGGL(bd_probe_read_kernel<8>, dim3(grid), dim3(256), 0, st, p, bytes / 16, sink, (int)contiguous);
+    else if (depth == 16) hipLaunchKernelGGL(bd_probe_read_kernel<16>, dim3(grid), dim3(256), 0, st, p, bytes / 16, sink, (int)contiguous);
+    else if (depth == 2) hipLaunchKernelGGL(bd_probe_read_kernel<2>, dim3(grid), dim3(256), 0, st, p, bytes / 16, sink, (int)contiguous);
+    else hipLaunchKernelGGL(bd_probe_read_kernel<4>, dim3(grid), dim3(256), 0, st, p, bytes / 16, sink, (int)contiguous);
     return bd_check_hip(hipGetLastError(), "launch bd_probe_read_kernel");
+}
+
+extern "C" int bd_probe_read(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu, void *hip_stream)
+{
+    return bd_probe_read_ex(src, bytes, sink, waves_per_cu, 4, 0, hip_stream);
 }

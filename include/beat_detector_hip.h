@@ -339,6 +339,10 @@ const char *bd_last_kernel_name(void);
  * ceiling those kernels are compared with.  `sink` (device, 256 * waves_per_cu
  * dwords, may be NULL) receives one word per wavefront. */
 int bd_probe_read(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu, void *hip_stream);
+/* The same with `depth` (2, 4, 8 or 16) loads per lane in flight and, with `contiguous`
+ * set, one contiguous share of the buffer per wavefront instead of side-by-side sweeps. */
+int bd_probe_read_ex(const void *src, uint64_t bytes, uint32_t *sink, uint32_t waves_per_cu,
+                     uint32_t depth, uint32_t contiguous, void *hip_stream);
 
 #ifdef __cplusplus
 }
