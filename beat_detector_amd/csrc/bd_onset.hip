@@ -537,6 +537,8 @@ extern "C" int bd_onset_pick(uint32_t sampling_rate, const bd_onset_params *p, c
     if ((!flux && n_frames) || !onset_count) { bd_set_error("bd_onset_pick: flux and onset_count must not be NULL"); return BD_ERR_INVALID_ARG; }
     if (n_streams == 0) return BD_OK;
     if (flux_stride == 0) flux_stride = n_frames;
+    if (flux_stride < n_frames) { bd_set_error("bd_onset_pick: flux_stride < n_frames"); return BD_ERR_INVALID_ARG; }
+    if (max_onsets == 0 && (onset_frame || onset_ms)) { bd_set_error("bd_onset_pick: max_onsets is 0"); return BD_ERR_INVALID_ARG; }
     bd_pick_args a;
     a.flux = flux; a.cand = candidates; a.count = onset_count; a.frame = onset_frame; a.ms = onset_ms;
     a.out_stride = flux_stride; a.n_frames = n_frames; a.n_streams = n_streams;
