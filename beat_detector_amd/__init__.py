@@ -34,6 +34,7 @@ from .api import (  # noqa: F401
     lib_path,
     refractory,
     start_listening,
+    stereo_to_mono,
     synth_fill,
     synth_fill_host,
     u16_data_to_i16,

@@ -183,6 +183,7 @@ def lib() -> C.CDLL:
         "bd_refractory": (i32, [u32, pp, u32, vp, u64, u64, u64, vp, vp, vp, u32, vp]),
         "bd_u16_data_to_i16": (i32, [vp, vp, u64, vp]),
         "bd_f32_data_to_i16": (i32, [vp, vp, u64, vp]),
+        "bd_stereo_to_mono": (i32, [vp, vp, u64, vp]),
         "bd_synth_fill": (i32, [vp, u64, u64, u64, u64, u64, u32, vp]),
         "bd_synth_fill_host": (i32, [vp, u64, u64, u64, u64, u64, u32]),
         "bd_last_kernel_name": (C.c_char_p, []),
@@ -218,7 +219,7 @@ EXPORTED_SYMBOLS = (
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
-    "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_synth_fill "
+    "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
     "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope bd_probe_read bd_probe_read_ex"
@@ -546,6 +547,17 @@ def f32_data_to_i16(data, stream=None):
     out = torch.empty(data.shape, dtype=torch.int16, device=data.device)
     with torch.cuda.device(data.device):
         _check(lib().bd_f32_data_to_i16(data.data_ptr(), out.data_ptr(), data.numel(), _stream_ptr(stream)))
+    return out
+
+
+def stereo_to_mono(interleaved, stream=None):
+    """Interleaved stereo CUDA int16 tensor [..., 2 * n] -> mono [..., n] (src/lib.rs:310-337)."""
+    _require_cuda(interleaved, torch.int16, "interleaved")
+    if interleaved.shape[-1] % 2:
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "interleaved stereo needs an even number of samples")
+    out = torch.empty(interleaved.shape[:-1] + (interleaved.shape[-1] // 2,), dtype=torch.int16, device=interleaved.device)
+    with torch.cuda.device(interleaved.device):
+        _check(lib().bd_stereo_to_mono(interleaved.data_ptr(), out.data_ptr(), out.numel(), _stream_ptr(stream)))
     return out
 
 

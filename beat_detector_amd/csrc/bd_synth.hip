@@ -135,6 +135,29 @@ extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, voi
     return bd_check_hip(hipGetLastError(), "launch bd_f32_to_i16_kernel");
 }
 
+// Down-mix of interleaved stereo frames as the reference's test harness does it
+// (src/lib.rs:310-337: `((l as i32 + r as i32) as f32 / 2.0) as i16`, i.e. the sum halved
+// with truncation toward zero; the sum of two i16 is exact in f32).  One thread per frame,
+// a 4-byte load and a 2-byte store each.
+__global__ void bd_stereo_to_mono_kernel(const int16_t *in, int16_t *out, uint64_t n_frames)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_frames) return;
+    const int32_t sum = (int32_t)in[2 * i] + (int32_t)in[2 * i + 1];
+    out[i] = (int16_t)(sum / 2); // C division truncates toward zero, like the f32 -> i16 cast
+}
+
+extern "C" int bd_stereo_to_mono(const int16_t *interleaved, int16_t *mono, uint64_t n_frames, void *hip_stream)
+{
+    if ((!interleaved || !mono) && n_frames) { bd_set_error("bd_stereo_to_mono: null pointer"); return BD_ERR_INVALID_ARG; }
+    if (n_frames == 0) return BD_OK;
+    const uint64_t grid64 = (n_frames + 255) / 256;
+    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(bd_stereo_to_mono_kernel, dim3((unsigned)grid64), dim3(256), 0,
+                       (hipStream_t)hip_stream, interleaved, mono, n_frames);
+    return bd_check_hip(hipGetLastError(), "launch bd_stereo_to_mono_kernel");
+}
+
 // ---- read-bandwidth probe -----------------------------------------------------
 // The ceiling the sample-streaming kernels are measured against: the same 16-byte
 // non-temporal loads (256 contiguous bytes per 16 lanes), no arithmetic beyond an

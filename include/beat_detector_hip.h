@@ -242,6 +242,9 @@ int bd_listener_join(bd_listener *listener);
 /* ---- ingest converters, src/record.rs:151-166 (device pointers) -------- */
 int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, void *hip_stream);
 int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, void *hip_stream);
+/* Down-mix of interleaved stereo i16 frames, src/lib.rs:310-337 (the reference's
+ * test harness: (l + r) / 2 truncated toward zero).  Device pointers. */
+int bd_stereo_to_mono(const int16_t *interleaved, int16_t *mono, uint64_t n_frames, void *hip_stream);
 
 /* ---- deterministic synthetic click tracks (integer arithmetic only) ---- */
 /* Stream `first_stream + s` gets the same samples whatever batch it is

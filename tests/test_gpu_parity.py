@@ -295,6 +295,16 @@ def test_converters_match_reference(bd, oracle):
     np.testing.assert_array_equal(got, oracle.f32_data_to_i16(f))
 
 
+def test_stereo_downmix_matches_reference(bd, oracle):
+    torch = _torch()
+    rng = np.random.default_rng(5)
+    st = rng.integers(-32768, 32768, (3, 2 * 5001)).astype(np.int16)
+    st[0, :8] = [-32768, -32768, 32767, 32767, -1, 0, 1, -2]          # extremes and odd sums of either sign
+    got = bd.stereo_to_mono(torch.from_numpy(st).cuda()).cpu().numpy()
+    for r in range(3):
+        np.testing.assert_array_equal(got[r], oracle.stereo_to_mono(st[r]))
+
+
 def test_generator_device_equals_host(bd):
     torch = _torch()
     for n_streams, n, first in ((5, 44100 * 3 + 5, 0), (3, 1000, 77), (2, 8, 5), (1, 7, 2)):
