@@ -414,7 +414,7 @@ struct bd_pick_args {
     uint32_t    *count, *frame, *ms;
     uint64_t     out_stride, n_frames, n_streams;
     uint32_t     mean_frames, max_frames, min_gap_ms, max_onsets;
-    uint32_t     fft_len, hop, sampling_rate;
+    uint32_t     fft_len, hop, sampling_rate, use_median;
     float        delta, lambda;
 };
 
@@ -435,7 +435,19 @@ __global__ __launch_bounds__(256) void bd_peak_pick_kernel(bd_pick_args a)
             const int64_t hi = j + a.mean_frames < n - 1 ? j + a.mean_frames : n - 1;
             float sum = 0.f;
             for (int64_t i = lo; i <= hi; i++) sum += fl[i];
-            const float mean = sum / (float)(hi - lo + 1);
+            float mean = sum / (float)(hi - lo + 1);
+            if (a.use_median) { // element c/2 of the sorted window, found by counting ranks
+                const int64_t c = hi - lo + 1;
+                for (int64_t i = lo; i <= hi; i++) {
+                    const float vi = fl[i];
+                    int64_t rank = 0;
+                    for (int64_t k = lo; k <= hi; k++) {
+                        const float vk = fl[k];
+                        rank += (vk < vi || (vk == vi && k < i)) ? 1 : 0;
+                    }
+                    if (rank == c / 2) mean = vi;
+                }
+            }
             const float thr = __builtin_fmaf(a.lambda, mean, a.delta);
             const int64_t mlo = j > a.max_frames ? j - a.max_frames : 0;
             const int64_t mhi = j + a.max_frames < n - 1 ? j + a.max_frames : n - 1;
@@ -473,6 +485,7 @@ extern "C" void bd_onset_default_params(bd_onset_params *p)
     if (!p) return;
     p->fft_len = 2048; p->hop = 1024; p->window = 1; p->band_max_hz = 90.0f;
     p->mean_frames = 8; p->max_frames = 3; p->delta = 0.0f; p->lambda = 1.5f; p->min_gap_ms = 100;
+    p->use_median = 0;
 }
 
 extern "C" uint64_t bd_onset_frames(uint64_t n_samples, uint32_t fft_len, uint32_t hop)
@@ -544,7 +557,8 @@ extern "C" int bd_onset_pick(uint32_t sampling_rate, const bd_onset_params *p, c
     a.out_stride = flux_stride; a.n_frames = n_frames; a.n_streams = n_streams;
     a.mean_frames = p->mean_frames; a.max_frames = p->max_frames; a.min_gap_ms = p->min_gap_ms;
     a.max_onsets = max_onsets; a.fft_len = p->fft_len; a.hop = p->hop; a.sampling_rate = sampling_rate;
-    a.delta = p->delta; a.lambda = p->lambda;
+    a.delta = p->delta; a.lambda = p->lambda; a.use_median = p->use_median ? 1u : 0u;
+    if (a.use_median && p->mean_frames > 32) { bd_set_error("bd_onset_pick: the median threshold supports mean_frames <= 32"); return BD_ERR_UNSUPPORTED; }
     const uint64_t grid64 = (n_streams + 3) / 4;
     if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(bd_peak_pick_kernel, dim3((unsigned)grid64), dim3(256), 0, (hipStream_t)hip_stream, a);

@@ -100,6 +100,7 @@ pub struct bd_onset_params {
     pub delta: f32,
     pub lambda: f32,
     pub min_gap_ms: u32,
+    pub use_median: u32,
 }
 
 /// `bd_biquad_params` of the C header.

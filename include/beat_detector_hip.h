@@ -276,6 +276,8 @@ typedef struct bd_onset_params {
     float    delta;        /* threshold = delta + lambda * mean */
     float    lambda;
     uint32_t min_gap_ms;   /* onsets closer than this to the previous one are dropped */
+    uint32_t use_median;   /* 1: the threshold follows the median of flux[j-W .. j+W] (element c/2 of the
+                              sorted window of c values) instead of the mean; W <= 32 */
 } bd_onset_params;
 void bd_onset_default_params(bd_onset_params *p);
 /* complete frames of a stream: 0 if n_samples < fft_len, else (n_samples - fft_len) / hop + 1 */

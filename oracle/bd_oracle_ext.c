@@ -55,6 +55,7 @@ void bdo_onset_default_params(bdo_onset_params *p)
     p->delta = 0.0f;
     p->lambda = 1.5f;
     p->min_gap_ms = 100;
+    p->use_median = 0;
 }
 
 size_t bdo_onset_frames(size_t n_samples, uint32_t fft_len, uint32_t hop)
@@ -212,7 +213,17 @@ size_t bdo_onset_pick(const float *flux, size_t n_frames, uint32_t sampling_rate
         const size_t hi = j + p->mean_frames < n_frames - 1 ? j + p->mean_frames : n_frames - 1;
         float sum = 0.0f;
         for (size_t i = lo; i <= hi; i++) sum += flux[i];
-        const float mean = sum / (float)(hi - lo + 1);
+        float mean = sum / (float)(hi - lo + 1);
+        if (p->use_median) {
+            /* element c/2 of the sorted window; equal values keep their order (any choice gives the same value) */
+            const size_t c = hi - lo + 1;
+            for (size_t i = lo; i <= hi; i++) {
+                size_t rank = 0;
+                for (size_t k = lo; k <= hi; k++)
+                    if (flux[k] < flux[i] || (flux[k] == flux[i] && k < i)) rank++;
+                if (rank == c / 2) mean = flux[i];
+            }
+        }
         const float thr = fmaf(p->lambda, mean, p->delta);
         const size_t mlo = j > p->max_frames ? j - p->max_frames : 0;
         const size_t mhi = j + p->max_frames < n_frames - 1 ? j + p->max_frames : n_frames - 1;

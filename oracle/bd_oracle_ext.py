@@ -23,6 +23,7 @@ class OnsetParams(C.Structure):
         ("delta", C.c_float),
         ("lambda_", C.c_float),
         ("min_gap_ms", C.c_uint32),
+        ("use_median", C.c_uint32),
     ]
 
 

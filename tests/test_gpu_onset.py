@@ -77,7 +77,8 @@ def test_onsets_match_definition(bd, oracle_ext, fft_len):
     rows = _streams(13, n, seed=7)
     dev, host = _aligned_rows(rows)
     for kw in (dict(), dict(mean_frames=3, max_frames=1, delta=1000.0, lambda_=1.2, min_gap_ms=250),
-               dict(mean_frames=0, max_frames=0, delta=0.0, lambda_=0.5, min_gap_ms=0)):
+               dict(mean_frames=0, max_frames=0, delta=0.0, lambda_=0.5, min_gap_ms=0),
+               dict(use_median=1), dict(use_median=1, mean_frames=32, max_frames=2, lambda_=2.0, min_gap_ms=50)):
         p = bd.OnsetParams.default(fft_len=fft_len, **kw)
         op = oracle_ext.default_params(fft_len=fft_len, **kw)
         res = bd.onset_batch(SR, dev, n_samples=n, params=p)

@@ -86,6 +86,21 @@ def test_peak_picking_known_answer(oracle_ext):
     assert frame.tolist() == [2, 6]
 
 
+def test_median_threshold_known_answer(oracle_ext):
+    p = oracle_ext.default_params(mean_frames=2, max_frames=1, delta=0.5, lambda_=1.0, min_gap_ms=0, use_median=1)
+    flux = np.array([0, 0, 5, 0, 0, 0, 3, 3, 0, 0, 0.4, 0], dtype=np.float32)
+    cand, frame, _ = oracle_ext.onset_pick(flux, 44100, p)
+    # medians of the 5-frame windows are 0 everywhere except around the 3, 3 pair: thresholds 0.5;
+    # j = 10: 0.4 < 0.5 rejected; j = 6 wins the tie with j = 7
+    assert frame.tolist() == [2, 6]
+    # a spike does not lift a median threshold the way it lifts a mean threshold
+    flux = np.array([1, 1, 1, 1, 50, 1, 1.6, 1, 1, 1, 1], dtype=np.float32)
+    pm = oracle_ext.default_params(mean_frames=3, max_frames=1, delta=0.0, lambda_=1.5, min_gap_ms=0, use_median=0)
+    pd = oracle_ext.default_params(mean_frames=3, max_frames=1, delta=0.0, lambda_=1.5, min_gap_ms=0, use_median=1)
+    assert oracle_ext.onset_pick(flux, 44100, pm)[1].tolist() == [4]
+    assert oracle_ext.onset_pick(flux, 44100, pd)[1].tolist() == [4, 6]
+
+
 def test_clicks_are_found(oracle_ext):
     sr, period = 44100, 22050
     x = click_track(sr * 10, 5, sr=sr, period=period, noise=200)
