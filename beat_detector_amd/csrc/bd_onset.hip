@@ -43,7 +43,7 @@ struct bd_onset_args {
     uint32_t       window;      // 1 = Hann
 };
 
-#define BD_ONSET_MAX_RUN 128
+#define BD_ONSET_MAX_RUN 64
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -222,13 +222,19 @@ __device__ __forceinline__ void bd_wave_lds_sync()
 }
 
 template <int E>
-__global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
+__device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 {
     using C = bd_fft_cfg<E>;
     constexpr int M = C::M, LGE = C::LGE, N = C::N, LGN = C::LGN;
     __shared__ v2f tile_all[4][C::DATA_LEN];
     __shared__ v2f win_lds[E][64];   // window at samples 2 n, 2 n + 1 of point n = slot q of a lane
-    __shared__ float out_lds[4][2][BD_ONSET_MAX_RUN];
+    // (cos, sin)(2 pi (lane + 64 t) / N) of the post-processing: in LDS for N = 2048, where
+    // registers decide the occupancy (3 waves per SIMD), per lane in registers for N = 1024
+    constexpr bool TWP_LDS = (E == 16);
+    __shared__ v2f twp_lds[TWP_LDS ? E : 1][64];
+    // results of a run: N = 2048 keeps frame f0 + i in lane i (its LDS is what limits the blocks
+    // per CU), N = 1024 stages them in LDS (its registers are what limits the waves per SIMD)
+    __shared__ float out_lds[TWP_LDS ? 1 : 4][2][BD_ONSET_MAX_RUN];
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         w.x = __builtin_fmaf(-0.5f, bd_tw_cs<E>(i0 <= M ? i0 : N - i0).x, 0.5f);
         w.y = __builtin_fmaf(-0.5f, bd_tw_cs<E>(i1 <= M ? i1 : N - i1).x, 0.5f);
         win_lds[q][lane] = a.window ? w : v2f{1.f, 1.f};
+        if constexpr (TWP_LDS) twp_lds[q][lane] = bd_tw_cs<E>(lane + 64 * q);
     }
     __syncthreads();
     v2f *tile = tile_all[wave];
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
     constexpr int S2 = C::NS1, S3 = C::NS1 + C::NS2, CNT2 = 1 << C::NS2, CNT3 = 1 << C::NS3, GROUPS = E / CNT3;
     const int low = lane & ((1 << S2) - 1);
     const int high = lane >> S2;
-    v2f tw2[CNT2 - 1], tw3[GROUPS][CNT3 - 1], twp[E];
+    v2f tw2[CNT2 - 1], tw3[GROUPS][CNT3 - 1], twp[TWP_LDS ? 1 : E];
 #pragma unroll
     for (int t = 0; t < C::NS2; t++)
 #pragma unroll
@@ -267,8 +274,10 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
 #pragma unroll
             for (int jl = 0; jl < (1 << t); jl++)
                 tw3[g][(1 << t) - 1 + jl] = bd_tw_fwd<E>((lane + 64 * g + (jl << S3)) << (LGN - (S3 + t + 1)));
+    if constexpr (!TWP_LDS) {
 #pragma unroll
-    for (int t = 0; t < E; t++) twp[t] = bd_tw_cs<E>(lane + 64 * t);
+        for (int t = 0; t < E; t++) twp[t] = bd_tw_cs<E>(lane + 64 * t);
+    }
 
     // LDS addresses (in points): every access below is one of these plus a constant
     constexpr int PAD1 = C::PAD1, PAD2 = C::PAD2;
@@ -280,6 +289,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
     v2f *t4 = tile + lane;                                                    // mirror exchange: Z[lane + 64 t]
     const v2f *t5 = tile + M - lane;                                          //                  Z[M - lane - 64 t]
 
+    float keep_flux = 0.f, keep_band = 0.f;
     float prev[E], prev_m = 0.f; // doubled magnitudes of the previous frame: bins lane + 64 t, and bin M
 #pragma unroll
     for (int t = 0; t < E; t++) prev[t] = 0.f;
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         float xs[E], xs_m, x_min;
 #pragma unroll
         for (int t = 0; t < E; t++) {
-            const v2f y = bd_post_bin(z[t], bd_lds_read(t5 - 64 * t), twp[t]);
+            const v2f y = bd_post_bin(z[t], bd_lds_read(t5 - 64 * t), TWP_LDS ? bd_lds_read(&twp_lds[t][lane]) : twp[TWP_LDS ? 0 : t]);
             const float yi2 = y.y * y.y;
             xs[t] = __builtin_fmaf(y.x, y.x, yi2);
             x_min = t == 0 ? xs[0] : fminf(x_min, xs[t]);
@@ -384,24 +394,38 @@ __global__ __launch_bounds__(256) void bd_stft_flux_kernel(bd_onset_args a)
         prev_m = xs_m;
         const float flux = 0.5f * bd_butterfly_sum_lane63(flux_p);
         const float band = 0.25f * bd_butterfly_sum_lane63(band_p);
-        if (f >= f0 && lane == 63) {
+        // lane i keeps the results of frame f0 + i (run_frames <= 64)
+        const float flux_u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(flux), 63));
+        const float band_u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(band), 63));
+        if constexpr (TWP_LDS) {
+            if (f >= f0 && (uint64_t)lane == f - f0) { keep_flux = flux_u; keep_band = band_u; }
+        } else if (f >= f0 && lane == 63) {
             out_lds[wave][0][f - f0] = flux;
             out_lds[wave][1][f - f0] = band;
         }
     }
     // results of the run, contiguous
-    bd_wave_lds_sync();
+    if constexpr (!TWP_LDS) {
+        bd_wave_lds_sync();
+        if ((unsigned)lane < (unsigned)(f_end - f0)) { keep_flux = out_lds[wave][0][lane]; keep_band = out_lds[wave][1][lane]; }
+    }
     const unsigned n_res = (unsigned)(f_end - f0);
     const uint64_t o0 = s * a.out_stride + f0;
     if (a.flux) {
         __amdgpu_buffer_rsrc_t r = bd_out_rsrc(a.flux + o0, n_res * 4u);
-        for (unsigned i = lane; i < n_res; i += 64) bd_store_stream_f32(r, i * 4u, out_lds[wave][0][i]);
+        if ((unsigned)lane < n_res) bd_store_stream_f32(r, lane * 4u, keep_flux);
     }
     if (a.band) {
         __amdgpu_buffer_rsrc_t r = bd_out_rsrc(a.band + o0, n_res * 4u);
-        for (unsigned i = lane; i < n_res; i += 64) bd_store_stream_f32(r, i * 4u, out_lds[wave][1][i]);
+        if ((unsigned)lane < n_res) bd_store_stream_f32(r, lane * 4u, keep_band);
     }
 }
+
+// N = 2048 asks for three waves per SIMD (168 registers); N = 1024 leaves the
+// register count to the compiler (about 110, four waves per SIMD).
+template <int E> __global__ void bd_stft_flux_kernel(bd_onset_args a);
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16>(bd_onset_args a) { bd_stft_flux_body<16>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8>(bd_onset_args a) { bd_stft_flux_body<8>(a); }
 
 // ---- peak picking -----------------------------------------------------------
 // One wavefront per stream.  Lane = frame: moving mean of flux[j-W .. j+W]
