@@ -295,19 +295,28 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
     for (int t = 0; t < E; t++) prev[t] = 0.f;
 
     // raw points (two i16 per dword) of the current frame
-    unsigned raw[E];
+    // (two register sets that swap roles from frame to frame: slots of the first / second half)
+    unsigned raw_a[E / 2], raw_b[E / 2];
     const uint64_t f_first = f0 > 0 ? f0 - 1 : 0; // one frame of warm-up gives the flux its predecessor
     // rows need no alignment beyond that of a sample: dword loads at 2-byte-aligned addresses
     typedef unsigned bd_u32_a2 __attribute__((aligned(2)));
     const bd_u32_a2 *fp = reinterpret_cast<const bd_u32_a2 *>(sp + f_first * (uint64_t)M) + r6;
 #pragma unroll
-    for (int q = 0; q < E; q++) raw[q] = __builtin_nontemporal_load(fp + bd_rev_bits(q, LGE) * 64);
+    for (int q = 0; q < E; q += 2) {
+        raw_a[q / 2] = __builtin_nontemporal_load(fp + bd_rev_bits(q, LGE) * 64);
+        raw_b[q / 2] = __builtin_nontemporal_load(fp + bd_rev_bits(q + 1, LGE) * 64);
+    }
+    float prev_b[E];
 
-    for (uint64_t f = f_first; f < f_end; f++) {
+    // One frame.  ra / rb: raw points of the even / odd slots (first / second half of the frame);
+    // afterwards ra holds the odd slots of the next frame, whose even slots are rb.  pin: magnitudes
+    // of the previous frame, pout: those of this one.
+    auto frame = [&](const uint64_t f, unsigned (&ra)[E / 2], unsigned (&rb)[E / 2], float (&pin)[E], float (&pout)[E])
+        __attribute__((always_inline)) {
         v2f z[E];
 #pragma unroll
         for (int q = 0; q < E; q++) {
-            const int d = (int)raw[q];
+            const int d = (int)((q & 1) ? rb[q / 2] : ra[q / 2]);
             const v2f x = v2f{(float)(short)(d & 0xffff), (float)(short)(d >> 16)};
             z[q] = bd_lds_read(&win_lds[q][lane]) * x;   // (exact for the rectangular window: 1 * x)
         }
@@ -315,10 +324,7 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
         if (f + 1 < f_end) {
             const bd_u32_a2 *np = reinterpret_cast<const bd_u32_a2 *>(sp + (f + 1) * (uint64_t)M) + r6;
 #pragma unroll
-            for (int q = 0; q < E; q += 2) {
-                raw[q] = raw[q + 1];
-                raw[q + 1] = __builtin_nontemporal_load(np + bd_rev_bits(q + 1, LGE) * 64);
-            }
+            for (int q = 0; q < E; q += 2) ra[q / 2] = __builtin_nontemporal_load(np + bd_rev_bits(q + 1, LGE) * 64);
         }
         // phase 1: stages 1 .. NS1 on points E*lane .. E*lane + E - 1 (bit-reversed order)
         bd_fft_phase1<E>(z);
@@ -382,9 +388,9 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
         }
 #pragma unroll
         for (int t = 0; t < E; t++) {
-            const float d = xs[t] - prev[t];
-            flux_p += d > 0.f ? d : 0.f;
-            prev[t] = xs[t];
+            const float d = xs[t] - pin[t];
+            flux_p += fmaxf(d, 0.f);
+            pout[t] = xs[t];
         }
         if (lane == 0) {
             const float d = xs_m - prev_m;
@@ -403,6 +409,11 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
             out_lds[wave][0][f - f0] = flux;
             out_lds[wave][1][f - f0] = band;
         }
+    };
+    for (uint64_t f = f_first; f < f_end; f += 2) {
+        frame(f, raw_a, raw_b, prev, prev_b);
+        if (f + 1 >= f_end) break;
+        frame(f + 1, raw_b, raw_a, prev_b, prev);
     }
     // results of the run, contiguous
     if constexpr (!TWP_LDS) {
