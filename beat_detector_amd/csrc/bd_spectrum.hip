@@ -33,6 +33,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "bd_twiddles.inc"
+#include "bd_granule_tw.inc"
 
 typedef short bd_short2 __attribute__((ext_vector_type(2)));
 
@@ -340,6 +341,210 @@ __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generi
     }
 }
 
+// ---- window path ------------------------------------------------------------
+// Any callback length, kept bins 0 .. 2.  One wavefront walks up to 64 consecutive
+// callbacks of one stream whose ring lies inside the stream (the few callbacks
+// before that go to the generic kernel).  Per callback the wavefront reads the
+// ring with two 16-byte loads per lane at 2-byte-aligned addresses (2 KB
+// contiguous; overlapping rings of neighbouring callbacks come from the caches),
+// lane l owns ring positions 16 l .. 16 l + 15: pruned DFT with compile-time
+// twiddles w^{k i}, one rotation by the lane's w^{16 k l}, then one reduction
+// network for all four sums: two lane-half swaps and one row swap leave
+// (re1, re2, im1, im2) spread over the four rows of 16 lanes, and four DPP steps
+// finish them.  The amplitude gate is a ballot (some lane holds a sample of the
+// callback with |x| >= min_amplitude).  Sums are parked in LDS; at the end of the
+// run lane i turns callback i's sums into value and decision.
+struct bd_win_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride, out_stride, n_cb, n_tasks;
+    uint64_t       j_min;           // first callback whose ring starts inside the stream
+    uint32_t       runs_per_stream, callback_len;
+    uint32_t       min_amp, include_dc;
+    float          divisor, threshold;
+};
+
+// The two lane-swap instructions of gfx950, as assembly: with the builtins the compiler adds the
+// first result to itself when the operands are floats.  Two wait states separate a VALU write from
+// the swap that reads it.
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b.
+// v_permlane16_swap: rows 1, 3 of a <-> rows 0, 2 of b (rows of 16 lanes).
+template <typename T>
+__device__ __forceinline__ void bd_swap_halves(T &a, T &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+template <typename T>
+__device__ __forceinline__ void bd_swap_rows(T &a, T &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// lanes 0-31: a[l] + a[l + 32]; lanes 32-63: b[l - 32] + b[l]
+template <typename T>
+__device__ __forceinline__ T bd_halves_sum(T a, T b)
+{
+    bd_swap_halves(a, b);
+    return a + b;
+}
+// rows 0, 2: a[row] + a[row + 1]; rows 1, 3: b[row - 1] + b[row]   (lane by lane)
+template <typename T>
+__device__ __forceinline__ T bd_rows_sum(T a, T b)
+{
+    bd_swap_rows(a, b);
+    return a + b;
+}
+
+__device__ __forceinline__ void bd_win_absmax(float &m, float a, float b)
+{
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+}
+
+// NK: non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.  WHOLE: the callback's
+// own samples start on a lane boundary of the ring (callback length a multiple of 16, or >= 1024).
+template <int NK, bool NYQ, bool WHOLE>
+__global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
+{
+    __shared__ __attribute__((aligned(16))) float st_f[4][64][4];
+    __shared__ __attribute__((aligned(8))) int st_i[4][64][2];
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    if (task >= a.n_tasks) return;
+    const uint64_t s = task / a.runs_per_stream;
+    const uint64_t j0 = a.j_min + (task - s * a.runs_per_stream) * 64;
+    const uint64_t left = a.n_cb - j0;
+    const int n_win = left < 64 ? (int)left : 64;
+    const int16_t *sp = a.samples + s * a.stride;
+    const uint64_t L = a.callback_len;
+
+    // w^{16 k l}, w = exp(2 pi i / 1024) (conjugate DFT kernel: same magnitudes)
+    float lc[NK > 0 ? NK : 1], ls[NK > 0 ? NK : 1];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int ml = ((k + 1) * 16 * lane) & (BD_RING_LEN - 1);
+        lc[k] = bd_cos1024[ml]; ls[k] = bd_sin1024[ml];
+    }
+    // the callback's own samples are the ring positions >= own_from (spectrum.rs:77)
+    const int own_from = L < BD_RING_LEN ? BD_RING_LEN - (int)L : 0;
+    const int t_own = own_from - 16 * lane;   // this lane's positions i >= t_own count
+
+    typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+    bd_u32x4 n_lo, n_hi;
+    auto load = [&](uint64_t j) {
+        const u32x4_a2 *p = reinterpret_cast<const u32x4_a2 *>(sp + ((j + 1) * L - BD_RING_LEN) + 16 * lane);
+        n_lo = p[0]; n_hi = p[1];
+    };
+    load(j0);
+    uint64_t gate_mask = 0;
+    for (int i = 0; i < n_win; i++) {
+        const bd_u32x4 lo = n_lo, hi = n_hi;
+        if (i + 1 < n_win) load(j0 + i + 1);
+        const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        float x[16];
+        int dc = 0, ny = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int v = (int)w[q];
+            x[2 * q] = (float)(short)(v & 0xffff);
+            x[2 * q + 1] = (float)(short)(v >> 16);
+            dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, dc, false);
+            if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, -1}, ny, false);
+        }
+        // amplitude gate
+        float amax = 0.f;
+        if (WHOLE) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) bd_win_absmax(amax, x[2 * q], x[2 * q + 1]);
+            amax = t_own <= 0 ? amax : 0.f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                bd_win_absmax(amax, 2 * q >= t_own ? x[2 * q] : 0.f, 2 * q + 1 >= t_own ? x[2 * q + 1] : 0.f);
+        }
+        if (L > BD_RING_LEN) { // the part of a longer callback that lies before the ring
+            const int64_t end = (int64_t)((j0 + i + 1) * L);
+            for (int64_t idx = end - (int64_t)L + lane; idx < end - BD_RING_LEN; idx += 64)
+                amax = fmaxf(amax, fabsf((float)sp[idx]));
+        }
+        const bool gate = __builtin_amdgcn_ballot_w64(fminf(amax, 32767.f) >= (float)a.min_amp) != 0;
+        gate_mask |= gate ? (1ull << i) : 0ull;
+
+        // pruned DFT of the lane's 16 positions, rotated to the lane's place in the ring
+        if (NK > 0) {
+            float pr[NK > 0 ? NK : 1], pi[NK > 0 ? NK : 1];
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                float re = x[0], im = 0.f;
+#pragma unroll
+                for (int n = 1; n < 16; n++) {
+                    re = __builtin_fmaf(x[n], BD_GR_C[k][n], re);
+                    im = __builtin_fmaf(x[n], BD_GR_S[k][n], im);
+                }
+                pr[k] = __builtin_fmaf(re, lc[k], -(im * ls[k]));
+                pi[k] = __builtin_fmaf(re, ls[k], im * lc[k]);
+            }
+            // rows of 16 lanes end up with: NK = 2: (re1, re2, im1, im2); NK = 1: (re1, re1, im1, im1)
+            float v = bd_halves_sum(pr[0], pi[0]);
+            if (NK == 2) v = bd_rows_sum(v, bd_halves_sum(pr[1], pi[1]));
+            else v = bd_rows_sum(v, v);
+            v = bd_row_sum(v);
+            if ((lane & 15) == 0) st_f[wave][i][lane >> 4] = v;
+        }
+        {   // halves of 32 lanes end up with (dc, ny)
+            int v = bd_halves_sum(dc, NYQ ? ny : dc);
+            v = bd_rows_sum(v, v);
+            v = bd_row_sum(v);
+            if ((lane & 31) == 0) st_i[wave][i][lane >> 5] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane i finishes callback j0 + i
+    float value = 0.f;
+    bool flag = false;
+    if (lane < n_win) {
+        const float x_dc = (float)st_i[wave][lane][0];
+        float m0 = fabsf(x_dc);
+        if (NYQ) {
+            const float x_ny = (float)st_i[wave][lane][1];
+            m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
+        }
+        float best = a.include_dc ? m0 : 0.f;
+        if (NK >= 1) {
+            const float xr = st_f[wave][lane][0], xi = st_f[wave][lane][2];
+            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
+        }
+        if (NK >= 2) {
+            const float xr = st_f[wave][lane][1], xi = st_f[wave][lane][3];
+            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
+        }
+        value = (a.divisor == 0.f) ? best : best / a.divisor;
+        flag = ((gate_mask >> lane) & 1ull) && value > a.threshold;
+    }
+    const uint64_t o0 = s * a.out_stride + j0;
+    __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, (unsigned)n_win);
+    bd_store_stream_u8(rf, (unsigned)lane, flag ? 1 : 0);          // stores past n_win are dropped
+    if (a.values) {
+        __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values + o0, (unsigned)n_win * 4u);
+        bd_store_stream_f32(rv, (unsigned)lane * 4u, value);
+    }
+}
+
+template <int NK, bool NYQ>
+static void bd_win_launch2(bool whole, const bd_win_args &a, unsigned grid, hipStream_t st)
+{
+    if (whole) hipLaunchKernelGGL((bd_spectrum_window_kernel<NK, NYQ, true>), dim3(grid), dim3(256), 0, st, a);
+    else       hipLaunchKernelGGL((bd_spectrum_window_kernel<NK, NYQ, false>), dim3(grid), dim3(256), 0, st, a);
+}
+template <int NK>
+static void bd_win_launch(bool nyq, bool whole, const bd_win_args &a, unsigned grid, hipStream_t st)
+{
+    if (nyq) bd_win_launch2<NK, true>(whole, a, grid, st);
+    else     bd_win_launch2<NK, false>(whole, a, grid, st);
+}
+
 // ---- launcher ---------------------------------------------------------------
 template <int MODE, int NK>
 static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, unsigned lds_pad, hipStream_t st)
@@ -403,15 +608,44 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     if (fast_bins && callback_len % 64 == 0 && callback_len <= 4096 && !getenv("BD_SPEC_NO_GRANULE"))
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
-    bd_spec_generic_args a;
+    // everything else with the usual bins: the window kernel; the callbacks whose ring starts
+    // before the stream does (zeros, spectrum.rs:50-51) take the generic kernel
+    const bool window_path = fast_bins && !getenv("BD_SPEC_NO_GRANULE");
+    uint64_t n_generic = n_cb;
+    if (window_path) {
+        const uint64_t j_min = (BD_RING_LEN + callback_len - 1) / callback_len - 1; // callbacks with (j + 1) L < 1024
+        n_generic = j_min < n_cb ? j_min : n_cb;
+    }
+    if (n_generic > 0) {
+        bd_spec_generic_args a;
+        a.samples = samples; a.values = values; a.flags = flags;
+        a.stride = stride; a.n_cb = n_generic; a.n_total = n_streams * n_generic; a.out_stride = out_stride;
+        a.callback_len = callback_len; a.min_amp = plan.min_amp;
+        a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
+        a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;
+        const uint64_t grid64 = (a.n_total + 3) / 4;
+        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(bd_spectrum_generic_kernel, dim3((unsigned)grid64), dim3(256), 0, st, a);
+        bd_set_last_kernel("bd_spectrum_generic_kernel");
+        int rc = bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
+        if (rc != BD_OK || n_generic == n_cb) return rc;
+    }
+    bd_win_args a;
     a.samples = samples; a.values = values; a.flags = flags;
-    a.stride = stride; a.n_cb = n_cb; a.n_total = n_streams * n_cb; a.out_stride = out_stride;
-    a.callback_len = callback_len; a.min_amp = plan.min_amp;
-    a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
-    a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;
-    const uint64_t grid64 = (a.n_total + 3) / 4;
+    a.stride = stride; a.out_stride = out_stride; a.n_cb = n_cb; a.j_min = n_generic;
+    const uint64_t runs = (n_cb - n_generic + 63) / 64;
+    if (runs > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
+    a.runs_per_stream = (uint32_t)runs;
+    a.n_tasks = n_streams * runs;
+    a.callback_len = callback_len; a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
+    a.divisor = plan.divisor; a.threshold = plan.threshold;
+    const uint64_t grid64 = (a.n_tasks + 3) / 4;
     if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(bd_spectrum_generic_kernel, dim3((unsigned)grid64), dim3(256), 0, st, a);
-    bd_set_last_kernel("bd_spectrum_generic_kernel");
-    return bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
+    const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
+    const bool whole = callback_len % 16 == 0 || callback_len >= BD_RING_LEN;
+    if (plan.last_bin == 0) bd_win_launch<0>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin == 1) bd_win_launch<1>(nyq, whole, a, (unsigned)grid64, st);
+    else bd_win_launch<2>(nyq, whole, a, (unsigned)grid64, st);
+    bd_set_last_kernel("bd_spectrum_window_kernel");
+    return bd_check_hip(hipGetLastError(), "launch bd_spectrum_window_kernel");
 }

@@ -79,10 +79,34 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 317, 529, 700, 1500, 3000, 4160, 8192])
-def test_spectrum_generic_callback_lengths(bd, oracle, L):
+@pytest.mark.parametrize("L", [1, 7, 16, 100, 317, 441, 480, 529, 700, 882, 1000, 1023, 1025, 1500, 3000, 4160, 8192])
+def test_spectrum_window_callback_lengths(bd, oracle, L):
+    """Callback lengths that are not multiples of 64 (or lie above 4096): the window kernel, with the
+    callbacks whose ring starts before the stream on the generic kernel; streams of one callback, of a
+    few, of more than one run of 64 callbacks."""
+    for n, streams in ((40000, 2), (max(3 * L + 5, 1100), 3), (L, 2), (min(64 * L * 3 + 7, 300000), 1)):
+        x = _synth(bd, streams, n, first=3)
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+        n_cb = n // L
+        if (n_cb * L >= 1024):
+            assert bd.last_kernel_name() == "bd_spectrum_window_kernel"
+        else:
+            assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+    x = _synth(bd, 2, 50000, first=9)
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
+               dict(spectrum_max_hz=50.0), dict(spectrum_max_hz=10.0)):
+        _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+
+
+@pytest.mark.parametrize("L", [7, 441, 1000, 1500])
+def test_spectrum_generic_kernel_alone(bd, oracle, monkeypatch, L):
+    """The generic kernel on every callback (what sampling rates with more than three kept bins use)."""
+    monkeypatch.setenv("BD_SPEC_NO_GRANULE", "1")
     x = _synth(bd, 2, 40000, first=3)
     _compare(bd, oracle, "Spectrum", SR, x, L)
+    assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+    x = _synth(bd, 2, 30000, first=4, sr=8000)
+    _compare(bd, oracle, "Spectrum", 8000, x, L)
     assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
 
 
@@ -384,7 +408,7 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
     view[:, :n] = torch.from_numpy(x).cuda()
     assert view.data_ptr() % 4 == 2
     for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
-                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_generic_kernel"),
+                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_window_kernel"),
                                  ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
         kind = bd.StrategyKind[kind_name]
         okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF

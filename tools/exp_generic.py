@@ -8,7 +8,7 @@ buf = torch.empty((streams, stride), dtype=torch.int16, device="cuda")
 bd.synth_fill(buf, n_samples=n, seed=1)
 out = []
 for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
-    for L in (512, 1024, 256, 2048, 4096, 441, 1000, 128, 64):
+    for L in (512, 1024, 256, 2048, 4096, 441, 480, 882, 1000, 1500, 160, 128, 64):
         for _ in range(2):
             bd.batch_candidates(kind, sr, buf, L, n_samples=n)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
