@@ -65,7 +65,8 @@ __device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, 
     if (a.values) bd_store_stream_f32(bd_out_rsrc(a.values + o0, rows * 4u), (unsigned)lane * 4u, gate ? ymax : 0.f);
 }
 
-// ALIGNED: callback_len % 8 == 0, stride % 8 == 0, base 16-byte aligned.
+// ALIGNED: callback_len % 8 == 0, stride % 8 == 0, base 16-byte aligned; otherwise rows at any
+// 2-byte-aligned address, cut at the lines of memory.
 // WPB: wavefronts per workgroup (each has a private LDS tile).
 template <bool ALIGNED, int CHUNK, int WPB>
 __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
@@ -142,56 +143,87 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
             }
         }
     } else {
-        // Rows that are only 2-byte aligned (callback length not a multiple of 8, odd strides):
-        // the same staging with 16-byte loads at unaligned addresses (global memory allows
-        // them); the piece that straddles the end of a window is gathered sample by sample so
-        // that nothing past the window -- possibly past the buffer -- is touched.
-        typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+        // Rows at any 2-byte-aligned address (callback length not a multiple of 64, odd strides):
+        // every row is cut at the SEG-byte lines of memory it crosses, so that a line is fetched
+        // by one chunk of the row only, with 16-byte loads that are aligned again.  Chunk `ch` of
+        // row r is line `ch` of that row: its samples [lo, hi) belong to the window, where lo > 0
+        // only in the first line and hi < CHUNK only in the last.  A piece that reaches outside the
+        // analysed samples of the stream -- possibly outside the buffer -- is gathered sample by
+        // sample; pieces that merely reach into the neighbouring window are loaded whole.
+        constexpr uint32_t SEG = CHUNK * 2;
+        const uintptr_t g_addr = reinterpret_cast<uintptr_t>(gp);
+        const uintptr_t s_begin = reinterpret_cast<uintptr_t>(a.samples + s * a.stride);
+        const uintptr_t s_end = s_begin + 2 * a.n_cb * (uint64_t)L;
         const int lrow = lane / PIECES, piece = lane % PIECES;
+        const uint32_t n_lines = (L + 2 * BD_LPF_CHUNK - 2) / BD_LPF_CHUNK; // lines a row can touch
         uint4 stage[PIECES];
         auto load_chunk = [&](uint32_t ch) {
-            const uint32_t first = ch * BD_LPF_CHUNK + piece * 8; // sample offset inside the window
 #pragma unroll
             for (int i = 0; i < PIECES; i++) {
                 const uint32_t row = ROWS_PER_LOAD * i + lrow;
-                const int16_t *src = gp + (uint64_t)row * L + first;
                 uint4 v = make_uint4(0, 0, 0, 0);
-                if (row < rows && first + 8 <= L) {
-                    const bd_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a2 *>(src));
-                    v = make_uint4(t.x, t.y, t.z, t.w);
-                } else if (row < rows && first < L) {
-                    unsigned w[4] = {0, 0, 0, 0};
-                    for (uint32_t e = 0; e < L - first; e++) w[e >> 1] |= (unsigned)(uint16_t)src[e] << (16 * (e & 1));
-                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                if (row < rows) {
+                    const uintptr_t row_a = g_addr + 2 * (uint64_t)row * L, row_e = row_a + 2 * (uint64_t)L;
+                    const uintptr_t pa = (row_a & ~(uintptr_t)(SEG - 1)) + (uint64_t)ch * SEG + 16u * (uint32_t)piece;
+                    if (pa + 16 > row_a && pa < row_e) {
+                        if (pa >= s_begin && pa + 16 <= s_end) {
+                            v = bd_load_stream16(reinterpret_cast<const void *>(pa));
+                        } else {
+                            unsigned w[4] = {0, 0, 0, 0};
+                            for (uint32_t e = 0; e < 8; e++) {
+                                const uintptr_t ea = pa + 2 * e;
+                                if (ea >= row_a && ea < row_e)
+                                    w[e >> 1] |= (unsigned)*reinterpret_cast<const uint16_t *>(ea) << (16 * (e & 1));
+                            }
+                            v = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
                 }
                 stage[i] = v;
             }
         };
+        // this lane's window inside its lines
+        const uint32_t off = (uint32_t)((g_addr + 2 * (uint64_t)lane * L) & (SEG - 1)) / 2;
+        const uint32_t len = (uint64_t)lane < rows ? L : 0;
         load_chunk(0);
-        for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        for (uint32_t ch = 0; ch < n_lines; ch++) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < PIECES; i++)
                 tile[(ROWS_PER_LOAD * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
-            if (ch + 1 < n_chunks) load_chunk(ch + 1);
+            if (ch + 1 < n_lines) load_chunk(ch + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t left = L - ch * BD_LPF_CHUNK;
-            const int cnt = left >= (uint32_t)BD_LPF_CHUNK ? BD_LPF_CHUNK : (int)left;
-            for (int p = 0; p < cnt / 8; p++) {
-                const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
-                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t c0 = ch * BD_LPF_CHUNK;                       // first line position of the chunk
+            const uint32_t lo = off > c0 ? off - c0 : 0;
+            const uint32_t end = off + len;                               // line position after the window
+            const uint32_t hi = end > c0 ? (end - c0 < (uint32_t)BD_LPF_CHUNK ? end - c0 : (uint32_t)BD_LPF_CHUNK) : 0;
+            const bool whole = lo == 0 && hi == (uint32_t)BD_LPF_CHUNK;
+            if (__builtin_amdgcn_ballot_w64(!whole) == 0) {
+                for (int p = 0; p < PIECES; p++) {
+                    const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int d = (int)w[q];
-                    bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
-                    bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    for (int q = 0; q < 4; q++) {
+                        const int d = (int)w[q];
+                        bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                        bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    }
                 }
-            }
-            if (cnt & 7) {
-                const int16_t *t16 = reinterpret_cast<const int16_t *>(tile + lane * BD_LPF_ROW_U4 + cnt / 8);
-                for (int e = 0; e < (cnt & 7); e++) bd_lpf_step((float)t16[e], alpha, y, ymax, xmax);
+            } else {
+                const uint32_t span = hi > lo ? hi - lo : 0;
+                for (int p = 0; p < PIECES; p++) {
+                    const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                    const uint32_t rel = (uint32_t)(8 * p) - lo;                // position - lo (wraps below lo)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int d = (int)w[q];
+                        if (rel + 2 * q < span) bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                        if (rel + 2 * q + 1 < span) bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    }
+                }
             }
         }
     }
@@ -233,7 +265,11 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     a.n_tasks = n_streams * groups;
     a.callback_len = callback_len; a.min_amp = plan.min_amp;
     a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
-    const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0);
+    // Rows that keep their place inside a 128-byte line (callback length a multiple of 64) use the
+    // aligned staging; so do short callbacks, where the partial first and last lines of the line
+    // staging weigh more than the lines it saves (160: 4.7 vs 4.6 TB/s; 480: 5.3 vs 6.1; 1000: 4.8 vs 6.1).
+    const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0) &&
+                         (callback_len % 64 == 0 || callback_len < 256);
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
     const char *variant_str = getenv("BD_LPF_VARIANT");

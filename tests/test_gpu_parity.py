@@ -188,10 +188,13 @@ def test_lpf_aligned(bd, oracle, L):
         assert ref_c.sum() > 0
 
 
-@pytest.mark.parametrize("L", [1, 3, 317, 529, 1000, 1023, 1025, 4100])
+@pytest.mark.parametrize("L", [1, 3, 63, 65, 100, 127, 129, 160, 257, 317, 441, 480, 529, 882, 1000, 1023, 1025, 1500, 4100])
 def test_lpf_ragged(bd, oracle, L):
-    x = _synth(bd, 3, 50000 + L, first=9)
-    _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+    """Callback lengths off the 64-sample grid: rows start anywhere inside a 128-byte line; streams of
+    many windows, of one, of a partial group of 64, with an odd number of samples after the last."""
+    for n, streams in ((50000 + L, 3), (L, 2), (L * 5 + 3, 4), (min(L * 70 + 1, 200000), 1)):
+        x = _synth(bd, streams, n, first=9)
+        _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 
 
 def test_lpf_many_windows_per_stream(bd, oracle):
