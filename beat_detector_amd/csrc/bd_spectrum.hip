@@ -25,9 +25,10 @@
 //   half-block's sums come from the row above (row_bcast:15) or, for row 0,
 //   from the previous iteration (v_readlane 63).
 //
-// Generic kernel (any callback length, alignment or bin count)
-//   One wavefront per callback, ring gathered with 2-byte loads, twiddles from
-//   a 1024-entry table.
+// Window kernel (any callback length, bins 0..2): see the comment above it.
+//
+// Generic kernel (any callback length, alignment or bin count; stream starts)
+//   One wavefront per callback, twiddles from a 1024-entry table.
 #include "bd_internal.h"
 
 #include <stdio.h>
