@@ -604,9 +604,12 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         bd_set_last_kernel("bd_spectrum_band_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");
     }
-    // other multiples of 64 up to 4096: the granule kernel (BD_SPEC_NO_GRANULE=1 forces the generic one)
+    // other multiples of 64 up to 4096, of 32 up to 512, of 16 up to 256: the granule kernel
+    // (BD_SPEC_NO_GRANULE=1 forces the generic one, BD_SPEC_NO_SMALL_GRANULE=1 the window kernel
+    // for the lengths that need granules below 64 samples)
     // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)
-    if (fast_bins && callback_len % 64 == 0 && callback_len <= 4096 && !getenv("BD_SPEC_NO_GRANULE"))
+    if (fast_bins && bd_spectrum_granule_size(callback_len) != 0 && !getenv("BD_SPEC_NO_GRANULE") &&
+        !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
     // everything else with the usual bins: the window kernel; the callbacks whose ring starts

@@ -1,19 +1,20 @@
-// Spectrum strategy, batched, for callback lengths that are multiples of 64
-// samples (up to 4096) other than the two the half-block kernel covers: the value
+// Spectrum strategy, batched, for callback lengths that are multiples of 64, 32
+// or 16 samples (up to 4096, 512, 256) other than the two the half-block kernel covers: the value
 // of src/strategies/spectrum.rs:82-92 -- largest magnitude among the bins <= 90 Hz
 // of the 1024-point DFT of the latest 1024 samples -- and the decision of
 // spectrum.rs:77-92, one HBM read per sample.
 //
-// The stream is cut into granules of 64 samples; the ring of a callback is the 16
-// granules that end with it.  With P_k(g) = sum_{n<64} x[64 g + n] w^{k n},
-// w = exp(2 pi i / 1024) (the conjugate of the DFT kernel: magnitudes are the same),
-//     X_k(e) = sum_{i<16} w^{64 k i} P_k(e - 15 + i)
-// is built by four doubling levels
-//     Q^{j+1}(e) = Q^{j}(e - 2^j) + w^{64 k 2^j} Q^{j}(e),     Q^0 = P,  X = Q^4,
+// The stream is cut into granules of G = 64 samples (32 or 16 when the callback length
+// asks for it); the ring of a callback is the R = 1024 / G granules that end with it.
+// With P_k(g) = sum_{n<G} x[G g + n] w^{k n}, w = exp(2 pi i / 1024) (the conjugate
+// of the DFT kernel: magnitudes are the same),
+//     X_k(e) = sum_{i<R} w^{G k i} P_k(e - R + 1 + i)
+// is built by log2 R doubling levels
+//     Q^{j+1}(e) = Q^{j}(e - 2^j) + w^{G k 2^j} Q^{j}(e),     Q^0 = P,  X = Q^{log2 R},
 // so every granule is transformed once however the callbacks overlap the ring.
 //
-// One wavefront walks consecutive steps of 64 granules (8 KB) of one stream: coalesced
-// 16-byte loads, transposed through a private LDS tile (144-byte rows, conflict-free)
+// One wavefront walks consecutive steps of 64 granules (8 KB for G = 64) of one stream: coalesced
+// 16-byte loads, transposed through a private LDS tile (rows of 2 G + 16 bytes, conflict-free)
 // so that lane l owns granule l; per-lane pruned DFT with compile-time twiddles; the
 // doubling levels fetch lane l - 2^j from this step or, for the first lanes, from the
 // values the previous step left in registers.  The amplitude gate (max |x| over the
@@ -23,7 +24,6 @@
 #include "bd_internal.h"
 #include "bd_granule_tw.inc"
 
-#define BD_GR_ROW 36 /* dwords per LDS row: 128 B of samples + 16 B pad */
 
 typedef short bd_gr_short2 __attribute__((ext_vector_type(2)));
 
@@ -75,9 +75,15 @@ __device__ __forceinline__ int bd_gr_back(int cur, int prev, int lane, int d)
     return lane >= d ? c : p;
 }
 
-template <int NK, bool NYQ>
+// G: samples per granule (64, 32 or 16).
+template <int NK, bool NYQ, int G>
 __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
 {
+    constexpr int DW = G / 2;                 // dwords of samples per granule
+    constexpr int U4 = G / 8;                 // 16-byte units per granule
+    constexpr int BD_GR_ROW = DW + 4;         // dwords per LDS row: the samples + 16 B pad
+    constexpr int LV = G == 64 ? 4 : G == 32 ? 5 : 6;   // doubling levels: log2(1024 / G)
+    constexpr int LV0 = 6 - LV;               // first entry of the level table
     __shared__ __attribute__((aligned(16))) uint32_t tile_all[4][64 * BD_GR_ROW];
     __shared__ float out_v[4][128];
     __shared__ uint8_t out_f[4][128];
@@ -94,37 +100,38 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
     const uint64_t st0 = r * a.steps_per_run;
     const uint64_t st1 = st0 + a.steps_per_run < n_steps ? st0 + a.steps_per_run : n_steps;
     const uint64_t st_first = st0 > 0 ? st0 - 1 : 0;   // replayed step: fills the "previous step" values
-    const uint64_t last_unit = a.n_gran * 8 - 1;        // last 16-byte unit that belongs to a callback
+    const uint64_t last_unit = a.n_gran * U4 - 1;       // last 16-byte unit that belongs to a callback
     const uint32_t m = a.m;
     // sliding maximum over m granules = two overlapping windows of 2^lg granules
     const int lg = 31 - __builtin_clz(m);
     const int tail = (int)m - (1 << lg);
 
     const bool mis = a.misaligned != 0;
-    uint4 ld[8];
+    uint4 ld[U4];
     auto load_step = [&](uint64_t st) {
         if ((st + 1) * 64 <= a.n_gran) {
-            const int16_t *base = sp + st * 4096 + lane * 8;
+            const int16_t *base = sp + st * (64 * G) + lane * 8;
 #pragma unroll
-            for (int j = 0; j < 8; j++) ld[j] = bd_gr_load16(base + j * 512, mis);
+            for (int j = 0; j < U4; j++) ld[j] = bd_gr_load16(base + j * 512, mis);
         } else { // units past the analysed range are replaced by the last valid one (never reported)
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                uint64_t unit = st * 512 + (uint64_t)(j * 64 + lane);
+            for (int j = 0; j < U4; j++) {
+                uint64_t unit = st * (64 * U4) + (uint64_t)(j * 64 + lane);
                 unit = unit < last_unit ? unit : last_unit;
                 ld[j] = bd_gr_load16(sp + unit * 8, mis);
             }
         }
     };
     load_step(st_first);
-    uint4 *wr = reinterpret_cast<uint4 *>(tile + (lane >> 3) * BD_GR_ROW + (lane & 7) * 4); // + j * 8 rows
+    // unit j * 64 + lane of the step belongs to granule (j * 64 + lane) / U4, piece (j * 64 + lane) % U4
+    uint4 *wr = reinterpret_cast<uint4 *>(tile + (lane / U4) * BD_GR_ROW + (lane % U4) * 4); // + j * (64 / U4) rows
     const uint4 *rd = reinterpret_cast<const uint4 *>(tile + lane * BD_GR_ROW);
 
     // values of the previous step, per doubling level (zero = silence before the stream)
-    float p_re[4][NK > 0 ? NK : 1], p_im[4][NK > 0 ? NK : 1], p_amax[6];
-    int p_dc[4], p_ny[4];
+    float p_re[LV][NK > 0 ? NK : 1], p_im[LV][NK > 0 ? NK : 1], p_amax[6];
+    int p_dc[LV], p_ny[LV];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < LV; j++) {
         p_dc[j] = 0; p_ny[j] = 0;
 #pragma unroll
         for (int k = 0; k < (NK > 0 ? NK : 1); k++) { p_re[j][k] = 0.f; p_im[j][k] = 0.f; }
@@ -139,11 +146,11 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
     for (uint64_t st = st_first; st < st1; st++) {
         bd_gr_sync();
 #pragma unroll
-        for (int j = 0; j < 8; j++) wr[j * 8 * (BD_GR_ROW / 4)] = ld[j];
+        for (int j = 0; j < U4; j++) wr[j * (64 / U4) * (BD_GR_ROW / 4)] = ld[j];
         bd_gr_sync();
-        uint32_t raw[32];
+        uint32_t raw[DW];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
+        for (int c = 0; c < U4; c++) {
             const uint4 q = rd[c];
             raw[4 * c] = q.x; raw[4 * c + 1] = q.y; raw[4 * c + 2] = q.z; raw[4 * c + 3] = q.w;
         }
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
 #pragma unroll
         for (int k = 0; k < (NK > 0 ? NK : 1); k++) { re[k] = 0.f; im[k] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
+        for (int i = 0; i < DW; i++) {
             const int v = (int)raw[i];
             const float x0 = (float)(short)(v & 0xffff), x1 = (float)(short)(v >> 16);
             dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_gr_short2, v), bd_gr_short2{1, 1}, dc, false);
@@ -167,9 +174,9 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
                 re[k] = __builtin_fmaf(x1, BD_GR_C[k][2 * i + 1], re[k]); im[k] = __builtin_fmaf(x1, BD_GR_S[k][2 * i + 1], im[k]);
             }
         }
-        // doubling levels: 1 -> 16 granules
+        // doubling levels: 1 -> 1024 / G granules
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < LV; j++) {
             const int d = 1 << j;
             const int b_dc = bd_gr_back(dc, p_dc[j], lane, d);
             p_dc[j] = dc;
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
             for (int k = 0; k < NK; k++) {
                 const float b_re = bd_gr_back(re[k], p_re[j][k], lane, d), b_im = bd_gr_back(im[k], p_im[j][k], lane, d);
                 p_re[j][k] = re[k]; p_im[j][k] = im[k];
-                const float c = BD_GRL_C[k][j], sn = BD_GRL_S[k][j];
+                const float c = BD_GRL_C[k][LV0 + j], sn = BD_GRL_S[k][LV0 + j];
                 const float nr = b_re + (c * re[k] - sn * im[k]);
                 const float ni = b_im + (c * im[k] + sn * re[k]);
                 re[k] = nr; im[k] = ni;
@@ -243,15 +250,34 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
     }
 }
 
-template <int NK>
-static void bd_gr_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+template <int NK, int G>
+static void bd_gr_launch2(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
 {
-    if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, true>), dim3(grid), dim3(256), 0, st, a);
-    else     hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, false>), dim3(grid), dim3(256), 0, st, a);
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, true, G>), dim3(grid), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, false, G>), dim3(grid), dim3(256), 0, st, a);
+}
+template <int NK>
+static void bd_gr_launch(uint32_t gran, bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+{
+    if (gran == 64) bd_gr_launch2<NK, 64>(nyq, a, grid, st);
+    else if (gran == 32) bd_gr_launch2<NK, 32>(nyq, a, grid, st);
+    else bd_gr_launch2<NK, 16>(nyq, a, grid, st);
+}
+
+// Granule size for a callback length, 0 if the granule kernel does not take it: 64 for multiples
+// of 64 up to 4096; 32 for multiples of 32 up to 512 and 16 for multiples of 16 up to 256, where
+// the granule kernel beats the window kernel (measured, 2,048 streams x 60 s: 480: 4.3 vs 4.0 TB/s,
+// 160: 4.4 vs 1.6, 240: 2.5 vs 2.3; but 720 with granules of 16: 2.4 vs 5.3).
+uint32_t bd_spectrum_granule_size(uint32_t callback_len)
+{
+    if (callback_len % 64 == 0) return callback_len <= 4096 ? 64 : 0;
+    if (callback_len % 32 == 0) return callback_len <= 512 ? 32 : 0;
+    if (callback_len % 16 == 0) return callback_len <= 256 ? 16 : 0;
+    return 0;
 }
 
 // Returns BD_OK after enqueueing, or a negative status; the caller has checked that
-// callback_len is a multiple of 64 not above 4096 and the kept bins are 0 .. last_bin <= 2.
+// bd_spectrum_granule_size(callback_len) != 0 and the kept bins are 0 .. last_bin <= 2.
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
                                uint64_t out_stride, hipStream_t st)
@@ -260,7 +286,9 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     a.samples = samples; a.values = values; a.flags = flags;
     a.stride = stride; a.out_stride = out_stride;
     a.n_cb = n_samples / callback_len;
-    a.m = callback_len / 64;
+    const uint32_t gran = bd_spectrum_granule_size(callback_len);
+    if (gran == 0) { bd_set_error("callback length has no granule size"); return BD_ERR_INVALID_ARG; }
+    a.m = callback_len / gran;
     a.misaligned = (((uintptr_t)samples % 16) || (stride % 8)) ? 1u : 0u;
     a.n_gran = a.n_cb * a.m;
     const uint64_t n_steps = (a.n_gran + 63) / 64;
@@ -276,9 +304,9 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     if (grid64 > 0x7fffffffull || n_steps > 0xffffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
     const unsigned grid = (unsigned)grid64;
-    if (plan.last_bin == 0) bd_gr_launch<0>(nyq, a, grid, st);
-    else if (plan.last_bin == 1) bd_gr_launch<1>(nyq, a, grid, st);
-    else bd_gr_launch<2>(nyq, a, grid, st);
+    if (plan.last_bin == 0) bd_gr_launch<0>(gran, nyq, a, grid, st);
+    else if (plan.last_bin == 1) bd_gr_launch<1>(gran, nyq, a, grid, st);
+    else bd_gr_launch<2>(gran, nyq, a, grid, st);
     bd_set_last_kernel("bd_spectrum_granule_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_spectrum_granule_kernel");
 }

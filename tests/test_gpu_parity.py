@@ -79,7 +79,7 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 16, 100, 317, 441, 480, 529, 700, 882, 1000, 1023, 1025, 1500, 3000, 4160, 8192])
+@pytest.mark.parametrize("L", [1, 7, 100, 317, 441, 529, 700, 720, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
 def test_spectrum_window_callback_lengths(bd, oracle, L):
     """Callback lengths that are not multiples of 64 (or lie above 4096): the window kernel, with the
     callbacks whose ring starts before the stream on the generic kernel; streams of one callback, of a
@@ -110,9 +110,11 @@ def test_spectrum_generic_kernel_alone(bd, oracle, monkeypatch, L):
     assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
 
 
-@pytest.mark.parametrize("L", [64, 128, 192, 256, 448, 960, 1536, 2048, 3008, 4096])
+@pytest.mark.parametrize("L", [64, 128, 192, 256, 448, 960, 1536, 2048, 3008, 4096,
+                               32, 96, 160, 480, 16, 48, 240])
 def test_spectrum_granule_callback_lengths(bd, oracle, L):
-    """Multiples of 64 other than 512 / 1024: the granule kernel; short streams, partial steps,
+    """Multiples of 64 other than 512 / 1024, of 32 up to 512 and of 16 up to 256: the granule kernel
+    (granules of 64, 32, 16 samples); short streams, partial steps,
     a stream long enough to be split into runs, and the generic kernel on the same data."""
     for n, streams in ((40000, 3), (4096 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4096 * 40 + 5, 1)):
         x = _synth(bd, streams, n, first=3)
@@ -129,7 +131,7 @@ def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
     import torch
     x = torch.from_numpy(np.ascontiguousarray(np.pad(_synth(bd, 4, 4096 * 9 + 100, first=1), ((0, 0), (0, 28))))).cuda()
     n = 4096 * 9 + 100
-    for L in (256, 2048, 704):
+    for L in (256, 2048, 704, 480, 240):
         v1, f1 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
         monkeypatch.setenv("BD_SPEC_NO_GRANULE", "1")
         v2, f2 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
