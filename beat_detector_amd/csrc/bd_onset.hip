@@ -89,23 +89,28 @@ __device__ __forceinline__ int bd_rev_bits(int v, int bits)
 }
 
 // Packed-f32 helpers.  The VOP3P source modifiers (op_sel picks the half of a
-// register pair, neg_lo / neg_hi negate one half) make a complex multiply two
-// instructions and every butterfly four; the compiler does not form them from
-// vector shuffles, hence the inline assembly.  All are single IEEE operations
-// per half, in the order the arithmetic specification gives.
+// register pair, neg_lo / neg_hi negate one half) make a general butterfly three
+// instructions; the compiler does not form them from vector shuffles, hence the
+// inline assembly.  All are single IEEE operations per half, in the order the
+// arithmetic specification gives.
 //
-// t = w * b with w = (wr, wi):  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
-__device__ __forceinline__ v2f bd_cmul(v2f b, v2f w)
+// General butterfly with twiddle w = (wr, wi):
+//     u = (fma(b.re, wr, a.re), fma(b.re, wi, a.im))
+//     X = (fma(-b.im, wi, u.re), fma(b.im, wr, u.im))          = a + w b
+//     Y = (fma(2, a.re, -X.re), fma(2, a.im, -X.im))           = a - w b
+__device__ __forceinline__ void bd_bfly_w(v2f &a, v2f &b, v2f w)
 {
-    v2f t;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
-        : "=&v"(t) : "v"(b), "v"(w));
-    return t;
+    v2f x, y;
+    asm("v_pk_fma_f32 %0, %2, %3, %1 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(x) : "v"(a), "v"(b), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(y) : "v"(a), "v"(x));
+    a = x; b = y;
 }
-__device__ __forceinline__ void bd_bfly(v2f &a, v2f &b, v2f t)
+// butterfly with twiddle (1, 0): X = a + b, Y = a - b
+__device__ __forceinline__ void bd_bfly_one(v2f &a, v2f &b)
 {
-    const v2f x = a;
+    const v2f x = a, t = b;
     a = x + t;
     b = x - t;
 }
@@ -119,21 +124,23 @@ __device__ __forceinline__ void bd_bfly_rot(v2f &a, v2f &b)
     a = ra; b = rb;
 }
 // Real-input post-processing of one bin (spectrum at twice its value):
-// z = Z[k], q = Z[M - k], cs = (cos, sin)(2 pi k / N); returns (Y.re, Y.im)
+// z = Z[k], q = Z[M - k], cs = (cos, sin)(2 pi k / N); returns (Y.re, Y.im) with
+//     e = (z.re + q.re, z.im - q.im),  d = (z.re - q.re, z.im + q.im)
+//     Y.re = fma(-s, d.re, fma(c, d.im, e.re)),  Y.im = fma(-s, d.im, fma(-c, d.re, e.im))
 __device__ __forceinline__ v2f bd_post_bin(v2f z, v2f q, v2f cs)
 {
     v2f e, d, y;
-    asm("v_pk_add_f32 %0, %3, %4 neg_hi:[0,1]\n\t"                                     // e = (zr + qr, zi - qi)
-        "v_pk_add_f32 %1, %3, %4 neg_lo:[0,1]\n\t"                                     // d = (zr - qr, zi + qi)
-        "v_pk_mul_f32 %2, %5, %1 op_sel_hi:[0,1]\n\t"                                  // (c dr, c di)
-        "v_pk_fma_f32 %2, %5, %1, %2 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]\n\t" // (fma(s,di,c dr), fma(-s,dr,c di))
-        "v_pk_add_f32 %2, %0, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"             // (er + qi, ei - pr)
+    asm("v_pk_add_f32 %0, %3, %4 neg_hi:[0,1]\n\t"                                              // e
+        "v_pk_add_f32 %1, %3, %4 neg_lo:[0,1]\n\t"                                              // d
+        "v_pk_fma_f32 %2, %5, %1, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]\n\t"        // (c di + er, -c dr + ei)
+        "v_pk_fma_f32 %2, %5, %1, %2 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" // (-s dr + ., -s di + .)
         : "=&v"(e), "=&v"(d), "=&v"(y) : "v"(z), "v"(q), "v"(cs));
     return y;
 }
 
 // Stages of the first phase (twiddle indices known at compile time).  Point q of
-// the lane, global stage s = t + 1; twiddles (1,0) and (0,-1) take the shortcut.
+// the lane, global stage s = t + 1; twiddles (1,0) and (0,-1) take the two-instruction forms
+// (in these stages only: the later ones use the general butterfly for every twiddle).
 template <int E>
 __device__ __forceinline__ void bd_fft_phase1(v2f *z)
 {
@@ -145,11 +152,9 @@ __device__ __forceinline__ void bd_fft_phase1(v2f *z)
             if (i & (1 << t)) continue;
             const int ib = i + (1 << t);
             const int idx = (i & ((1 << t) - 1)) << (C::LGN - (t + 1));
-            v2f tv;
-            if (idx == 0) tv = z[ib];
-            else if (idx == C::N / 4) { bd_bfly_rot(z[i], z[ib]); continue; }
-            else tv = bd_cmul(z[ib], bd_tw_fwd<E>(idx));
-            bd_bfly(z[i], z[ib], tv);
+            if (idx == 0) bd_bfly_one(z[i], z[ib]);
+            else if (idx == C::N / 4) bd_bfly_rot(z[i], z[ib]);
+            else bd_bfly_w(z[i], z[ib], bd_tw_fwd<E>(idx));
         }
     }
 }
@@ -162,17 +167,11 @@ __device__ __forceinline__ void bd_fft_phase(v2f *z, const v2f *tw)
     constexpr int H = 1 << (NS - 1);
 #pragma unroll
     for (int t = 0; t < NS; t++) {
-        v2f tv[H];
         // pair n: a = ((n >> t) << (t + 1)) + (n & ((1 << t) - 1)), b = a + (1 << t), twiddle jl = n & ((1 << t) - 1)
 #pragma unroll
         for (int n = 0; n < H; n++) {
-            const int jl = n & ((1 << t) - 1), ib = (((n >> t) << (t + 1)) + jl + (1 << t)) * STRIDE;
-            tv[n] = bd_cmul(z[ib], tw[(1 << t) - 1 + jl]);
-        }
-#pragma unroll
-        for (int n = 0; n < H; n++) {
             const int jl = n & ((1 << t) - 1), ia = (((n >> t) << (t + 1)) + jl) * STRIDE, ib = ia + (1 << t) * STRIDE;
-            bd_bfly(z[ia], z[ib], tv[n]);
+            bd_bfly_w(z[ia], z[ib], tw[(1 << t) - 1 + jl]);
         }
     }
 }

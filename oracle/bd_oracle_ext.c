@@ -11,22 +11,23 @@
  * 2. Complex sequence z[n] = (u[2n], u[2n+1]), n < M = N/2.
  * 3. Radix-2 decimation-in-time FFT of z: bit-reversal permutation, then stages
  *    s = 1 .. log2 M.  Butterfly on (a, b) with twiddle (wr, wi) =
- *    (cos, -sin)(2 pi j / 2^s) taken from BD_EXT_TW<N>[j * N / 2^s]:
- *        stage 1:  t = b
- *        stage 2:  t = b for j = 0,  t = (b.im, -b.re) for j = 1
- *        stage >= 3:  t.re = fma(-b.im, wi, b.re * wr),  t.im = fma(b.im, wr, b.re * wi)
- *        a' = a + t,  b' = a - t
- *    (A butterfly whose twiddle is exactly (1, 0) or (0, -1) may equally be evaluated
- *    with the shortcut of stage 1 / stage 2 or with the general formula: the two differ
- *    in the sign of zeros only, which no output depends on.)
+ *    (cos, -sin)(2 pi j / 2^s) taken from BD_EXT_TW<N>[j * N / 2^s].
+ *    In the first log2 M - 6 stages (4 for N = 2048, 3 for N = 1024) the twiddles (1, 0)
+ *    (j = 0) and (0, -1) (j = 2^s / 4) are exact:
+ *        t = b  resp.  t = (b.im, -b.re);      a' = a + t,  b' = a - t
+ *    Every other butterfly of these stages, and every butterfly of the later stages
+ *    whatever its twiddle, is the fused form (three packed instructions on the GPU):
+ *        u  = (fma(b.re, wr, a.re),   fma(b.re, wi, a.im))
+ *        a' = (fma(-b.im, wi, u.re),  fma(b.im, wr, u.im))           (= a + w b)
+ *        b' = (fma(2, a.re, -a'.re),  fma(2, a.im, -a'.im))          (= a - w b)
  * 4. Real-input post-processing, k = 0 .. M, with P = Z[k mod M], Q = Z[(M - k) mod M],
  *    (c, s) = BD_EXT_TW<N>[k].  The halving of the textbook formula is deferred: the
  *    spectrum is carried at twice its value (Y = 2 X) and the factor is applied once to
  *    each sum.
  *        er = P.re + Q.re              ei = P.im - Q.im
  *        dr = P.re - Q.re              di = P.im + Q.im
- *        pr = fma(s, di, c * dr)       qi = fma(-s, dr, c * di)
- *        Y.re = er + qi                Y.im = ei - pr
+ *        Y.re = fma(-s, dr, fma(c, di, er))
+ *        Y.im = fma(-s, di, fma(-c, dr, ei))
  *        m2[k] = sqrt(fma(Y.re, Y.re, Y.im * Y.im))             (= 2 |X[k]|)
  * 5. Sums over bins (flux, band energy) are taken as 64 interleaved partial sums
  *    (partial l adds the terms of k = l, l + 64, ... in ascending order, the term of
@@ -96,23 +97,31 @@ static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *m
         }
         re[r] = u0; im[r] = u1;
     }
+    /* The first lg - 6 stages (4 for N = 2048, 3 for N = 1024) take the exact forms X = a + t,
+     * Y = a - t for the twiddles (1, 0) and (0, -1); every other butterfly, and every butterfly
+     * of the later stages, is the fused form
+     *     u = (fma(b.re, wr, a.re), fma(b.re, wi, a.im))
+     *     X = (fma(-b.im, wi, u.re), fma(b.im, wr, u.im))
+     *     Y = (fma(2, a.re, -X.re), fma(2, a.im, -X.im))                                  */
+    const int exact_stages = lg - 6;
     for (int s = 1; s <= lg; s++) {
         const uint32_t len = 1u << s, half = len >> 1;
         for (uint32_t base = 0; base < m; base += len) {
             for (uint32_t j = 0; j < half; j++) {
                 const uint32_t a = base + j, b = a + half;
-                float tr, ti;
-                if (s == 1) { tr = re[b]; ti = im[b]; }
-                else if (s == 2) { if (j == 0) { tr = re[b]; ti = im[b]; } else { tr = im[b]; ti = -re[b]; } }
-                else {
-                    const float wr = tw[j * (n >> s)][0], wi = -tw[j * (n >> s)][1];
-                    const float p0 = re[b] * wr, p1 = re[b] * wi;
-                    tr = fmaf(-im[b], wi, p0);
-                    ti = fmaf(im[b], wr, p1);
-                }
                 const float ar = re[a], ai = im[a];
-                re[a] = ar + tr; im[a] = ai + ti;
-                re[b] = ar - tr; im[b] = ai - ti;
+                if (s <= exact_stages && (j == 0 || 4 * j == len)) {
+                    float tr, ti;
+                    if (j == 0) { tr = re[b]; ti = im[b]; } else { tr = im[b]; ti = -re[b]; }
+                    re[a] = ar + tr; im[a] = ai + ti;
+                    re[b] = ar - tr; im[b] = ai - ti;
+                } else {
+                    const float wr = tw[j * (n >> s)][0], wi = -tw[j * (n >> s)][1];
+                    const float ur = fmaf(re[b], wr, ar), ui = fmaf(re[b], wi, ai);
+                    const float xr = fmaf(-im[b], wi, ur), xi = fmaf(im[b], wr, ui);
+                    re[a] = xr; im[a] = xi;
+                    re[b] = fmaf(2.0f, ar, -xr); im[b] = fmaf(2.0f, ai, -xi);
+                }
             }
         }
     }
@@ -121,9 +130,8 @@ static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *m
         const float c = tw[k][0], s = tw[k][1];
         const float er = re[kp] + re[kq], ei = im[kp] - im[kq];
         const float dr = re[kp] - re[kq], di = im[kp] + im[kq];
-        const float cdr = c * dr, cdi = c * di;
-        const float pr = fmaf(s, di, cdr), qi = fmaf(-s, dr, cdi);
-        const float xr = er + qi, xi = ei - pr;
+        const float xr = fmaf(-s, dr, fmaf(c, di, er));
+        const float xi = fmaf(-s, di, fmaf(-c, dr, ei));
         const float xi2 = xi * xi;
         mag[k] = sqrtf(fmaf(xr, xr, xi2));
     }
