@@ -608,8 +608,12 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // (BD_SPEC_NO_GRANULE=1 forces the generic one, BD_SPEC_NO_SMALL_GRANULE=1 the window kernel
     // for the lengths that need granules below 64 samples)
     // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)
-    if (fast_bins && bd_spectrum_granule_size(callback_len) != 0 && !getenv("BD_SPEC_NO_GRANULE") &&
-        !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
+    // more bins than three (sampling rates below 32 kHz, down to 8 kHz): the granule kernel with
+    // granules of 64 samples, 512 and 1024 included
+    const bool many_bins_granule = !fast_bins && plan.last_bin <= BD_GR_MAX_BINS && callback_len % 64 == 0 &&
+                                   callback_len <= 4096;
+    if ((many_bins_granule || (fast_bins && bd_spectrum_granule_size(callback_len) != 0)) &&
+        !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
     // everything else with the usual bins: the window kernel; the callbacks whose ring starts

@@ -37,6 +37,7 @@ struct bd_gr_args {
     uint32_t       misaligned;      // rows are not 16-byte aligned: loads at 2-byte-aligned addresses
     uint32_t       steps_per_run, runs_per_stream;
     uint32_t       min_amp, include_dc;
+    uint32_t       nk_keep;         // non-DC bins that count (<= the NK the kernel evaluates)
     float          divisor, threshold;
 };
 
@@ -75,7 +76,9 @@ __device__ __forceinline__ int bd_gr_back(int cur, int prev, int lane, int d)
     return lane >= d ? c : p;
 }
 
-// G: samples per granule (64, 32 or 16).
+// G: samples per granule (64, 32 or 16).  NK: non-DC bins evaluated: 0 .. 2 at the usual sampling
+// rates; 3, 4, 5, 8 or 11 (G = 64 only) where the band up to 90 Hz holds more bins (sampling rates
+// down to 8 kHz), of which the first nk_keep count.
 template <int NK, bool NYQ, int G>
 __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
 {
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
             }
             float best = a.include_dc ? m0 : 0.f;
 #pragma unroll
-            for (int k = 0; k < NK; k++) best = fmaxf(best, sqrtf(re[k] * re[k] + im[k] * im[k]));
+            for (int k = 0; k < NK; k++)
+                if (NK <= 2 || k < (int)a.nk_keep) best = fmaxf(best, sqrtf(re[k] * re[k] + im[k] * im[k]));
             value = (a.divisor == 0.f) ? best : best / a.divisor;
             flag = fminf(gate_max, 32767.f) >= (float)a.min_amp && value > a.threshold;
         }
@@ -277,7 +281,8 @@ uint32_t bd_spectrum_granule_size(uint32_t callback_len)
 }
 
 // Returns BD_OK after enqueueing, or a negative status; the caller has checked that
-// bd_spectrum_granule_size(callback_len) != 0 and the kept bins are 0 .. last_bin <= 2.
+// bd_spectrum_granule_size(callback_len) != 0 and the kept bins are 0 .. last_bin with
+// last_bin <= 2, or last_bin <= BD_GR_MAX_BINS and a granule size of 64.
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
                                uint64_t out_stride, hipStream_t st)
@@ -304,9 +309,17 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     if (grid64 > 0x7fffffffull || n_steps > 0xffffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
     const unsigned grid = (unsigned)grid64;
+    a.nk_keep = (uint32_t)plan.last_bin;
+    if (plan.last_bin > 2 && gran != 64) { bd_set_error("more than three bins need granules of 64 samples"); return BD_ERR_UNSUPPORTED; }
     if (plan.last_bin == 0) bd_gr_launch<0>(gran, nyq, a, grid, st);
     else if (plan.last_bin == 1) bd_gr_launch<1>(gran, nyq, a, grid, st);
-    else bd_gr_launch<2>(gran, nyq, a, grid, st);
+    else if (plan.last_bin == 2) bd_gr_launch<2>(gran, nyq, a, grid, st);
+    else if (plan.last_bin == 3) bd_gr_launch2<3, 64>(nyq, a, grid, st);
+    else if (plan.last_bin == 4) bd_gr_launch2<4, 64>(nyq, a, grid, st);
+    else if (plan.last_bin == 5) bd_gr_launch2<5, 64>(nyq, a, grid, st);
+    else if (plan.last_bin <= 8) bd_gr_launch2<8, 64>(nyq, a, grid, st);
+    else if (plan.last_bin <= BD_GR_MAX_BINS) bd_gr_launch2<11, 64>(nyq, a, grid, st);
+    else { bd_set_error("too many bins for the granule kernel"); return BD_ERR_UNSUPPORTED; }
     bd_set_last_kernel("bd_spectrum_granule_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_spectrum_granule_kernel");
 }

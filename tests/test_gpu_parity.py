@@ -148,6 +148,22 @@ def test_spectrum_other_sampling_rates(bd, oracle, sr):
         _compare(bd, oracle, "Spectrum", sr, x, L)
 
 
+@pytest.mark.parametrize("sr", [8000, 11025, 12000, 16000, 22050, 24000])
+def test_spectrum_more_than_three_bins(bd, oracle, sr):
+    """Sampling rates whose band up to 90 Hz holds 4 to 12 bins: callback lengths on the 64-sample
+    grid (512 and 1024 included) take the granule kernel with that many bins; the unpinned choices too."""
+    x = _synth(bd, 3, 70000, first=5, sr=sr)
+    for L in (512, 1024, 256, 2048, 64, 4096):
+        _compare(bd, oracle, "Spectrum", sr, x, L)
+        assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
+               dict(spectrum_max_hz=60.0)):
+        _compare(bd, oracle, "Spectrum", sr, x, 512, bd.Params.default(**kw), oracle.default_params(**kw))
+    # below 8 kHz the band holds more bins than the granule kernel evaluates
+    _compare(bd, oracle, "Spectrum", 4000, _synth(bd, 2, 30000, first=1, sr=4000), 512)
+    assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
+
+
 def test_spectrum_unpinned_choices(bd, oracle):
     """Every documented choice for the third-party behaviour is implemented the
     same way on both sides."""
