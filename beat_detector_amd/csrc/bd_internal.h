@@ -45,6 +45,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
                        float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);
 #define BD_GR_MAX_BINS 11 // non-DC bins the granule kernel can evaluate (granules of 64 samples)
 uint32_t bd_spectrum_granule_size(uint32_t callback_len);
+int bd_spectrum_granule_max_bins(uint32_t gran);
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                                uint64_t n_samples, uint64_t stride, uint32_t callback_len,
                                float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);

@@ -363,6 +363,7 @@ struct bd_win_args {
     uint64_t       j_min;           // first callback whose ring starts inside the stream
     uint32_t       runs_per_stream, callback_len;
     uint32_t       min_amp, include_dc;
+    uint32_t       nk_keep;         // non-DC bins that count (<= the NK the kernel evaluates)
     float          divisor, threshold;
 };
 
@@ -401,12 +402,15 @@ __device__ __forceinline__ void bd_win_absmax(float &m, float a, float b)
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
 }
 
-// NK: non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.  WHOLE: the callback's
-// own samples start on a lane boundary of the ring (callback length a multiple of 16, or >= 1024).
+// NK: non-DC bins evaluated: 0 .. 2 at the usual sampling rates; 3, 4, 5, 8 or 11 where the band
+// up to 90 Hz holds more bins (down to 8 kHz), of which the first nk_keep count.  Bins go through
+// the reduction network in pairs.  NYQ: bin 0 carries the Nyquist sum.  WHOLE: the callback's own
+// samples start on a lane boundary of the ring (callback length a multiple of 16, or >= 1024).
 template <int NK, bool NYQ, bool WHOLE>
 __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
 {
-    __shared__ __attribute__((aligned(16))) float st_f[4][64][4];
+    constexpr int PAIRS = (NK + 1) / 2;
+    __shared__ __attribute__((aligned(16))) float st_f[4][64][PAIRS > 0 ? PAIRS : 1][4];
     __shared__ __attribute__((aligned(8))) int st_i[4][64][2];
 
     const int lane = threadIdx.x & 63;
@@ -486,12 +490,16 @@ __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
                 pr[k] = __builtin_fmaf(re, lc[k], -(im * ls[k]));
                 pi[k] = __builtin_fmaf(re, ls[k], im * lc[k]);
             }
-            // rows of 16 lanes end up with: NK = 2: (re1, re2, im1, im2); NK = 1: (re1, re1, im1, im1)
-            float v = bd_halves_sum(pr[0], pi[0]);
-            if (NK == 2) v = bd_rows_sum(v, bd_halves_sum(pr[1], pi[1]));
-            else v = bd_rows_sum(v, v);
-            v = bd_row_sum(v);
-            if ((lane & 15) == 0) st_f[wave][i][lane >> 4] = v;
+            // bins k, k + 1 of a pair: the rows of 16 lanes end up with (re_k, re_k+1, im_k, im_k+1);
+            // a last single bin with (re, re, im, im)
+#pragma unroll
+            for (int pp = 0; pp < PAIRS; pp++) {
+                float v = bd_halves_sum(pr[2 * pp], pi[2 * pp]);
+                if (2 * pp + 1 < NK) v = bd_rows_sum(v, bd_halves_sum(pr[2 * pp + 1 < NK ? 2 * pp + 1 : 0], pi[2 * pp + 1 < NK ? 2 * pp + 1 : 0]));
+                else v = bd_rows_sum(v, v);
+                v = bd_row_sum(v);
+                if ((lane & 15) == 0) st_f[wave][i][pp][lane >> 4] = v;
+            }
         }
         {   // halves of 32 lanes end up with (dc, ny)
             int v = bd_halves_sum(dc, NYQ ? ny : dc);
@@ -513,13 +521,12 @@ __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
             m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
         }
         float best = a.include_dc ? m0 : 0.f;
-        if (NK >= 1) {
-            const float xr = st_f[wave][lane][0], xi = st_f[wave][lane][2];
-            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
-        }
-        if (NK >= 2) {
-            const float xr = st_f[wave][lane][1], xi = st_f[wave][lane][3];
-            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            if (NK <= 2 || k < (int)a.nk_keep) {
+                const float xr = st_f[wave][lane][k / 2][k & 1], xi = st_f[wave][lane][k / 2][2 + (k & 1)];
+                best = fmaxf(best, sqrtf(xr * xr + xi * xi));
+            }
         }
         value = (a.divisor == 0.f) ? best : best / a.divisor;
         flag = ((gate_mask >> lane) & 1ull) && value > a.threshold;
@@ -608,17 +615,16 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // (BD_SPEC_NO_GRANULE=1 forces the generic one, BD_SPEC_NO_SMALL_GRANULE=1 the window kernel
     // for the lengths that need granules below 64 samples)
     // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)
-    // more bins than three (sampling rates below 32 kHz, down to 8 kHz): the granule kernel with
-    // granules of 64 samples, 512 and 1024 included
-    const bool many_bins_granule = !fast_bins && plan.last_bin <= BD_GR_MAX_BINS && callback_len % 64 == 0 &&
-                                   callback_len <= 4096;
-    if ((many_bins_granule || (fast_bins && bd_spectrum_granule_size(callback_len) != 0)) &&
+    // (more bins than three -- sampling rates below 32 kHz, down to 8 kHz -- as far as the granule
+    // size allows; 512 and 1024 included then)
+    const uint32_t gran = bd_spectrum_granule_size(callback_len);
+    if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) &&
         !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
-    // everything else with the usual bins: the window kernel; the callbacks whose ring starts
+    // everything else with at most 12 kept bins: the window kernel; the callbacks whose ring starts
     // before the stream does (zeros, spectrum.rs:50-51) take the generic kernel
-    const bool window_path = fast_bins && !getenv("BD_SPEC_NO_GRANULE");
+    const bool window_path = plan.last_bin <= BD_GR_MAX_BINS && !getenv("BD_SPEC_NO_GRANULE");
     uint64_t n_generic = n_cb;
     if (window_path) {
         const uint64_t j_min = (BD_RING_LEN + callback_len - 1) / callback_len - 1; // callbacks with (j + 1) L < 1024
@@ -651,9 +657,15 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
     const bool whole = callback_len % 16 == 0 || callback_len >= BD_RING_LEN;
+    a.nk_keep = (uint32_t)plan.last_bin;
     if (plan.last_bin == 0) bd_win_launch<0>(nyq, whole, a, (unsigned)grid64, st);
     else if (plan.last_bin == 1) bd_win_launch<1>(nyq, whole, a, (unsigned)grid64, st);
-    else bd_win_launch<2>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin == 2) bd_win_launch<2>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin == 3) bd_win_launch<3>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin == 4) bd_win_launch<4>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin == 5) bd_win_launch<5>(nyq, whole, a, (unsigned)grid64, st);
+    else if (plan.last_bin <= 8) bd_win_launch<8>(nyq, whole, a, (unsigned)grid64, st);
+    else bd_win_launch<11>(nyq, whole, a, (unsigned)grid64, st);
     bd_set_last_kernel("bd_spectrum_window_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_spectrum_window_kernel");
 }

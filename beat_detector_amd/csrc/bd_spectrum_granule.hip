@@ -77,8 +77,8 @@ __device__ __forceinline__ int bd_gr_back(int cur, int prev, int lane, int d)
 }
 
 // G: samples per granule (64, 32 or 16).  NK: non-DC bins evaluated: 0 .. 2 at the usual sampling
-// rates; 3, 4, 5, 8 or 11 (G = 64 only) where the band up to 90 Hz holds more bins (sampling rates
-// down to 8 kHz), of which the first nk_keep count.
+// rates; 3, 4, 5, 8 or 11 where the band up to 90 Hz holds more bins (sampling rates down to 8 kHz;
+// at most 8 with G = 32, 5 with G = 16), of which the first nk_keep count.
 template <int NK, bool NYQ, int G>
 __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
 {
@@ -280,9 +280,16 @@ uint32_t bd_spectrum_granule_size(uint32_t callback_len)
     return 0;
 }
 
+// Most non-DC bins the kernel evaluates with granules of `gran` samples (the doubling levels of
+// every bin live in registers: fewer bins where there are more levels).
+int bd_spectrum_granule_max_bins(uint32_t gran)
+{
+    return gran == 64 ? BD_GR_MAX_BINS : gran == 32 ? 8 : gran == 16 ? 5 : -1;
+}
+
 // Returns BD_OK after enqueueing, or a negative status; the caller has checked that
 // bd_spectrum_granule_size(callback_len) != 0 and the kept bins are 0 .. last_bin with
-// last_bin <= 2, or last_bin <= BD_GR_MAX_BINS and a granule size of 64.
+// last_bin <= bd_spectrum_granule_max_bins(granule size).
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
                                uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
                                uint64_t out_stride, hipStream_t st)
@@ -310,16 +317,15 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
     const unsigned grid = (unsigned)grid64;
     a.nk_keep = (uint32_t)plan.last_bin;
-    if (plan.last_bin > 2 && gran != 64) { bd_set_error("more than three bins need granules of 64 samples"); return BD_ERR_UNSUPPORTED; }
+    if (plan.last_bin > bd_spectrum_granule_max_bins(gran)) { bd_set_error("too many bins for this granule size"); return BD_ERR_UNSUPPORTED; }
     if (plan.last_bin == 0) bd_gr_launch<0>(gran, nyq, a, grid, st);
     else if (plan.last_bin == 1) bd_gr_launch<1>(gran, nyq, a, grid, st);
     else if (plan.last_bin == 2) bd_gr_launch<2>(gran, nyq, a, grid, st);
-    else if (plan.last_bin == 3) bd_gr_launch2<3, 64>(nyq, a, grid, st);
-    else if (plan.last_bin == 4) bd_gr_launch2<4, 64>(nyq, a, grid, st);
-    else if (plan.last_bin == 5) bd_gr_launch2<5, 64>(nyq, a, grid, st);
-    else if (plan.last_bin <= 8) bd_gr_launch2<8, 64>(nyq, a, grid, st);
-    else if (plan.last_bin <= BD_GR_MAX_BINS) bd_gr_launch2<11, 64>(nyq, a, grid, st);
-    else { bd_set_error("too many bins for the granule kernel"); return BD_ERR_UNSUPPORTED; }
+    else if (plan.last_bin == 3) bd_gr_launch<3>(gran, nyq, a, grid, st);
+    else if (plan.last_bin == 4) bd_gr_launch<4>(gran, nyq, a, grid, st);
+    else if (plan.last_bin == 5) bd_gr_launch<5>(gran, nyq, a, grid, st);
+    else if (plan.last_bin <= 8) { if (gran == 64) bd_gr_launch2<8, 64>(nyq, a, grid, st); else bd_gr_launch2<8, 32>(nyq, a, grid, st); }
+    else bd_gr_launch2<11, 64>(nyq, a, grid, st);
     bd_set_last_kernel("bd_spectrum_granule_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_spectrum_granule_kernel");
 }

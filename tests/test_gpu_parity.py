@@ -156,6 +156,15 @@ def test_spectrum_more_than_three_bins(bd, oracle, sr):
     for L in (512, 1024, 256, 2048, 64, 4096):
         _compare(bd, oracle, "Spectrum", sr, x, L)
         assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
+    for L in (441, 1000, 5000, 800):       # off the grids of the granule kernel: the window kernel
+        _compare(bd, oracle, "Spectrum", sr, x, L)
+        assert bd.last_kernel_name() == "bd_spectrum_window_kernel"
+    for L, max_bins in ((160, 8), (480, 8), (96, 8), (240, 5), (48, 5)):   # granules of 32 / 16 samples
+        _compare(bd, oracle, "Spectrum", sr, x, L)
+        last_bin = oracle.bin_range(sr, oracle.default_params())[2]
+        assert bd.last_kernel_name() == ("bd_spectrum_granule_kernel" if last_bin <= max_bins else "bd_spectrum_window_kernel")
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_max_hz=60.0)):
+        _compare(bd, oracle, "Spectrum", sr, x, 441, bd.Params.default(**kw), oracle.default_params(**kw))
     for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
                dict(spectrum_max_hz=60.0)):
         _compare(bd, oracle, "Spectrum", sr, x, 512, bd.Params.default(**kw), oracle.default_params(**kw))

@@ -11,7 +11,7 @@ for sr in (44100, 24000, 22050, 16000, 11025, 8000):
     row = []
     for env in ({}, {"BD_SPEC_NO_GRANULE": "1"}):
         os.environ.pop("BD_SPEC_NO_GRANULE", None); os.environ.update(env)
-        for L in (512, 1024):
+        for L in (512, 1024, 160, 441):
             for _ in range(2):
                 bd.batch_candidates(bd.StrategyKind.Spectrum, sr, buf, L, n_samples=n)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
