@@ -1,6 +1,6 @@
 // Extension analysis (no counterpart in the reference, which keeps three raw
 // FFT bins and a constant threshold: src/strategies/spectrum.rs:82-92):
-// Hann-windowed STFT of 1024 or 2048 points with hop = half the length,
+// Hann-windowed STFT of 1024 or 2048 points with hop = half or a quarter of the length,
 // low-band energy, spectral flux, adaptive-threshold peak picking.
 //
 // STFT kernel.  One wavefront owns a run of consecutive frames of one stream and
@@ -11,14 +11,13 @@
 //     (4+4+2 stages for E = 16, 3+3+3 for E = 8) with two exchanges through a
 //     padded LDS tile; the bit-reversal is folded into the global loads (lane L,
 //     slot q loads complex point rev(q) * 64 + rev6(L): every load instruction
-//     still covers 256 contiguous bytes), and because hop = N/2 the raw points of
-//     a frame's second half are kept in registers for the next frame, so each
-//     sample is read from memory once;
+//     still covers 256 contiguous bytes), and the raw points of the quarters a
+//     frame shares with the next one (two for hop = N/2, three for hop = N/4) are
+//     kept in registers, so each sample is read from memory once;
 //   * twiddles of the first phase are compile-time constants, those of the later
 //     phases and of the post-processing are prepared per lane in registers; the
 //     window comes from a table in LDS;
-//   * complex arithmetic on packed f32 instructions (a complex multiply is two, a
-//     butterfly four);
+//   * complex arithmetic on packed f32 instructions (a general butterfly is three);
 //   * real-input post-processing pairs Z[k] with Z[M-k] through LDS, magnitudes
 //     stay in registers for the next frame's flux; sums over bins are per-lane
 //     partial sums + a butterfly on the DPP network.
@@ -220,11 +219,13 @@ __device__ __forceinline__ void bd_wave_lds_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int E>
+// HQ: hop in quarters of the frame (2: hop = N / 2, 1: hop = N / 4).
+template <int E, int HQ>
 __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 {
     using C = bd_fft_cfg<E>;
     constexpr int M = C::M, LGE = C::LGE, N = C::N, LGN = C::LGN;
+    constexpr int HOP = M * HQ / 2;            // samples between frames
     __shared__ v2f tile_all[4][C::DATA_LEN];
     __shared__ v2f win_lds[E][64];   // window at samples 2 n, 2 n + 1 of point n = slot q of a lane
     // (cos, sin)(2 pi (lane + 64 t) / N) of the post-processing: in LDS for N = 2048, where
@@ -293,37 +294,49 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 #pragma unroll
     for (int t = 0; t < E; t++) prev[t] = 0.f;
 
-    // raw points (two i16 per dword) of the current frame
-    // (two register sets that swap roles from frame to frame: slots of the first / second half)
-    unsigned raw_a[E / 2], raw_b[E / 2];
+    // Raw points (two i16 per dword) of the current frame, one register set per quarter of the
+    // frame: slot q of the lane is point rev(q) * 64 + rev6(lane), so its quarter is given by the
+    // two low bits of q.  The sets change roles from frame to frame instead of being copied.
+    constexpr int EQ = E / 4;
+    unsigned raw_a[EQ], raw_b[EQ], raw_c[EQ], raw_d[EQ];
     const uint64_t f_first = f0 > 0 ? f0 - 1 : 0; // one frame of warm-up gives the flux its predecessor
     // rows need no alignment beyond that of a sample: dword loads at 2-byte-aligned addresses
     typedef unsigned bd_u32_a2 __attribute__((aligned(2)));
-    const bd_u32_a2 *fp = reinterpret_cast<const bd_u32_a2 *>(sp + f_first * (uint64_t)M) + r6;
+    const bd_u32_a2 *fp = reinterpret_cast<const bd_u32_a2 *>(sp + f_first * (uint64_t)HOP) + r6;
 #pragma unroll
-    for (int q = 0; q < E; q += 2) {
-        raw_a[q / 2] = __builtin_nontemporal_load(fp + bd_rev_bits(q, LGE) * 64);
-        raw_b[q / 2] = __builtin_nontemporal_load(fp + bd_rev_bits(q + 1, LGE) * 64);
+    for (int m = 0; m < EQ; m++) {   // slots 4 m + 0, 2, 1, 3 = quarters 0, 1, 2, 3
+        raw_a[m] = __builtin_nontemporal_load(fp + bd_rev_bits(4 * m, LGE) * 64);
+        raw_b[m] = __builtin_nontemporal_load(fp + bd_rev_bits(4 * m + 2, LGE) * 64);
+        raw_c[m] = __builtin_nontemporal_load(fp + bd_rev_bits(4 * m + 1, LGE) * 64);
+        raw_d[m] = __builtin_nontemporal_load(fp + bd_rev_bits(4 * m + 3, LGE) * 64);
     }
     float prev_b[E];
 
-    // One frame.  ra / rb: raw points of the even / odd slots (first / second half of the frame);
-    // afterwards ra holds the odd slots of the next frame, whose even slots are rb.  pin: magnitudes
-    // of the previous frame, pout: those of this one.
-    auto frame = [&](const uint64_t f, unsigned (&ra)[E / 2], unsigned (&rb)[E / 2], float (&pin)[E], float (&pout)[E])
-        __attribute__((always_inline)) {
+    // One frame.  r0 .. r3: raw points of its four quarters; afterwards the sets that the next frame
+    // no longer needs (r0, and r1 for hop = N / 2) hold the next frame's last quarter(s).  pin:
+    // magnitudes of the previous frame, pout: those of this one.
+    auto frame = [&](const uint64_t f, unsigned (&r0)[EQ], unsigned (&r1)[EQ], unsigned (&r2)[EQ], unsigned (&r3)[EQ],
+                     float (&pin)[E], float (&pout)[E]) __attribute__((always_inline)) {
         v2f z[E];
 #pragma unroll
         for (int q = 0; q < E; q++) {
-            const int d = (int)((q & 1) ? rb[q / 2] : ra[q / 2]);
+            const int c = ((q & 1) << 1) | ((q >> 1) & 1);
+            const int d = (int)(c == 0 ? r0[q >> 2] : c == 1 ? r1[q >> 2] : c == 2 ? r2[q >> 2] : r3[q >> 2]);
             const v2f x = v2f{(float)(short)(d & 0xffff), (float)(short)(d >> 16)};
             z[q] = bd_lds_read(&win_lds[q][lane]) * x;   // (exact for the rectangular window: 1 * x)
         }
-        // next frame: its first half is this frame's second half (odd slots -> even slots)
+        // the quarters the next frame adds
         if (f + 1 < f_end) {
-            const bd_u32_a2 *np = reinterpret_cast<const bd_u32_a2 *>(sp + (f + 1) * (uint64_t)M) + r6;
+            const bd_u32_a2 *np = reinterpret_cast<const bd_u32_a2 *>(sp + (f + 1) * (uint64_t)HOP) + r6;
 #pragma unroll
-            for (int q = 0; q < E; q += 2) ra[q / 2] = __builtin_nontemporal_load(np + bd_rev_bits(q + 1, LGE) * 64);
+            for (int m = 0; m < EQ; m++) {
+                if (HQ == 2) {
+                    r0[m] = __builtin_nontemporal_load(np + bd_rev_bits(4 * m + 1, LGE) * 64);   // its quarter 2
+                    r1[m] = __builtin_nontemporal_load(np + bd_rev_bits(4 * m + 3, LGE) * 64);   // its quarter 3
+                } else {
+                    r0[m] = __builtin_nontemporal_load(np + bd_rev_bits(4 * m + 3, LGE) * 64);   // its quarter 3
+                }
+            }
         }
         // phase 1: stages 1 .. NS1 on points E*lane .. E*lane + E - 1 (bit-reversed order)
         bd_fft_phase1<E>(z);
@@ -410,9 +423,19 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
         }
     };
     for (uint64_t f = f_first; f < f_end; f += 2) {
-        frame(f, raw_a, raw_b, prev, prev_b);
+        frame(f, raw_a, raw_b, raw_c, raw_d, prev, prev_b);
         if (f + 1 >= f_end) break;
-        frame(f + 1, raw_b, raw_a, prev_b, prev);
+        if (HQ == 2) {
+            frame(f + 1, raw_c, raw_d, raw_a, raw_b, prev_b, prev);
+        } else {
+            frame(f + 1, raw_b, raw_c, raw_d, raw_a, prev_b, prev);
+            // two frames on, the quarters are (c, d, a, b): rename by exchanging the sets
+#pragma unroll
+            for (int m = 0; m < EQ; m++) {
+                const unsigned ta = raw_a[m], tb = raw_b[m];
+                raw_a[m] = raw_c[m]; raw_b[m] = raw_d[m]; raw_c[m] = ta; raw_d[m] = tb;
+            }
+        }
     }
     // results of the run, contiguous
     if constexpr (!TWP_LDS) {
@@ -433,9 +456,11 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 
 // N = 2048 asks for three waves per SIMD (168 registers); N = 1024 leaves the
 // register count to the compiler (about 110, four waves per SIMD).
-template <int E> __global__ void bd_stft_flux_kernel(bd_onset_args a);
-template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16>(bd_onset_args a) { bd_stft_flux_body<16>(a); }
-template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8>(bd_onset_args a) { bd_stft_flux_body<8>(a); }
+template <int E, int HQ> __global__ void bd_stft_flux_kernel(bd_onset_args a);
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 2>(bd_onset_args a) { bd_stft_flux_body<16, 2>(a); }
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 1>(bd_onset_args a) { bd_stft_flux_body<16, 1>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 2>(bd_onset_args a) { bd_stft_flux_body<8, 2>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 1>(bd_onset_args a) { bd_stft_flux_body<8, 1>(a); }
 
 // ---- peak picking -----------------------------------------------------------
 // One wavefront per stream.  Lane = frame: moving mean of flux[j-W .. j+W]
@@ -531,8 +556,8 @@ extern "C" uint64_t bd_onset_frames(uint64_t n_samples, uint32_t fft_len, uint32
 static int bd_onset_check(const bd_onset_params *p, uint32_t sampling_rate)
 {
     if (!p) { bd_set_error("onset parameters must not be NULL"); return BD_ERR_INVALID_ARG; }
-    if ((p->fft_len != 1024 && p->fft_len != 2048) || p->hop != p->fft_len / 2) {
-        bd_set_error("fft_len must be 1024 or 2048 and hop = fft_len / 2");
+    if ((p->fft_len != 1024 && p->fft_len != 2048) || (p->hop != p->fft_len / 2 && p->hop != p->fft_len / 4)) {
+        bd_set_error("fft_len must be 1024 or 2048 and hop = fft_len / 2 or fft_len / 4");
         return BD_ERR_UNSUPPORTED;
     }
     if (sampling_rate == 0) { bd_set_error("sampling rate must be positive"); return BD_ERR_INVALID_ARG; }
@@ -568,8 +593,14 @@ extern "C" int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, c
     const uint64_t grid64 = (a.n_tasks + 3) / 4;
     if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)hip_stream;
-    if (p->fft_len == 2048) hipLaunchKernelGGL(bd_stft_flux_kernel<16>, dim3((unsigned)grid64), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(bd_stft_flux_kernel<8>, dim3((unsigned)grid64), dim3(256), 0, s, a);
+    const bool half = p->hop == p->fft_len / 2;
+    if (p->fft_len == 2048) {
+        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<16, 2>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((bd_stft_flux_kernel<16, 1>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+    } else {
+        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<8, 2>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((bd_stft_flux_kernel<8, 1>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+    }
     bd_set_last_kernel("bd_stft_flux_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_stft_flux_kernel");
 }

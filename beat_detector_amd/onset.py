@@ -3,7 +3,7 @@
 No counterpart in the reference (its Spectrum strategy keeps three raw FFT bins
 of an unwindowed ring and compares their maximum with a constant,
 src/strategies/spectrum.rs:82-92).  Hann STFT of 1024 or 2048 points with
-hop = half the length, low-band energy, spectral flux and adaptive-threshold
+hop = half or a quarter of the length, low-band energy, spectral flux and adaptive-threshold
 peak picking; all computed by ``libbeatdet_hip.so`` (`bd_onset_*`).
 """
 from __future__ import annotations

@@ -47,7 +47,12 @@ WORKLOADS = {
     "onset_1024": ("Onset", 512, 4096, 300,
                    "Extension mode: 4,096 synthetic 5-min tracks per GPU, 1024-pt Hann STFT hop 512, spectral flux + "
                    "band energy + adaptive peak picking"),
+    "onset_2048_hop512": ("Onset", 512, 4096, 300,
+                          "Extension mode: 4,096 synthetic 5-min tracks per GPU, 2048-pt Hann STFT hop 512 (75 % "
+                          "overlap), spectral flux + band energy + adaptive peak picking"),
 }
+# FFT length of the onset workloads (callback_len is their hop)
+ONSET_FFT = {"onset_2048": 2048, "onset_1024": 1024, "onset_2048_hop512": 2048}
 
 
 def main() -> None:
@@ -110,9 +115,10 @@ def main() -> None:
 
     samples = torch.empty((streams, stride), dtype=torch.int16, device=dev)
     bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=seed, sampling_rate=sr)
+    nfft = ONSET_FFT.get(args.workload, 0)
     if onset:
-        oparams = bd.OnsetParams.default(fft_len=2 * L)
-        n_cb = bd.onset_frames(n, 2 * L)                 # frames per track
+        oparams = bd.OnsetParams.default(fft_len=nfft, hop=L)
+        n_cb = bd.onset_frames(n, nfft, L)               # frames per track
         max_beats = max(1, (n * 1000 // sr) // max(oparams.min_gap_ms, 1) + 1)
     else:
         n_cb = n // L
@@ -212,11 +218,11 @@ def main() -> None:
     # belongs to a callback read once (2 B) + 5 B written per callback
     alg_bytes = streams * (n_cb * L * 2 + n_cb * 5)
     if onset:  # every sample of a complete frame once + flux and band energy (8 B) per frame
-        alg_bytes = streams * ((n_cb + 1) * L * 2 + n_cb * 8) if n_cb else 0
+        alg_bytes = streams * (((n_cb - 1) * L + nfft) * 2 + n_cb * 8) if n_cb else 0
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
 
     result = {
-        "metric": "audio-sec analysed/sec (node), " + {"Spectrum": "1024-pt STFT", "Onset": "%d-pt STFT" % (2 * L),
+        "metric": "audio-sec analysed/sec (node), " + {"Spectrum": "1024-pt STFT", "Onset": "%d-pt STFT" % nfft,
                                                        "LPF": "lowpass windows",
                                                        "Biquad": "carried-state biquad"}[kind_name],
         "value": value,
@@ -261,7 +267,6 @@ def main() -> None:
     if onset:
         # a full FFT per frame is bounded by f32 vector throughput as well: 2.5 N log2 N flops per real FFT
         # against the packed-FMA vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2 at 2.4 GHz)
-        nfft = 2 * L
         flops = streams * n_cb * 2.5 * nfft * (nfft.bit_length() - 1)
         peak_tflops = 256 * 4 * 16 * 2 * 2 * 2.4e9 / 1e12
         result["roofline"]["valu"] = {"achieved": flops / (k1_ms * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s",
@@ -270,7 +275,7 @@ def main() -> None:
     if result["roofline"].get("note") is None:
         result["roofline"].pop("note", None)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(bd, kind_name, samples, n, L, sr, min(args.cpu_streams, streams))
+        cb = cpu_baseline(bd, kind_name, samples, n, L, sr, min(args.cpu_streams, streams), nfft=nfft)
         # the GPU's count over the same streams (equal counts are a full-size consistency check, not the parity test)
         cb["gpu_events_same_sample"] = int(count[:cb.pop("_n")].sum().item())
         result["cpu_baseline"] = cb
@@ -296,11 +301,11 @@ def _pmc_traffic(workload, streams, seconds):
     return None
 
 
-def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams):
+def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams, nfft=0):
     """The CPU restatement of the reference (oracle/, a port: the Rust original
     cannot be built here) on the first `n_streams` streams of the same batch."""
     if kind_name == "Onset":
-        return cpu_baseline_onset(samples, n, L, sr, min(n_streams, 128))
+        return cpu_baseline_onset(samples, n, L, nfft, sr, min(n_streams, 128))
     if kind_name == "Biquad":
         return cpu_baseline_biquad(samples, n, L, sr, min(n_streams, 512))
     from oracle import bd_oracle
@@ -375,7 +380,7 @@ def cpu_baseline_biquad(samples, n, L, sr, n_streams):
     }
 
 
-def cpu_baseline_onset(samples, n, hop, sr, n_streams):
+def cpu_baseline_onset(samples, n, hop, nfft, sr, n_streams):
     """The CPU definition of the extension analysis (oracle/bd_oracle_ext.c) on the
     first `n_streams` tracks; ctypes releases the GIL, one track per task."""
     from concurrent.futures import ThreadPoolExecutor
@@ -386,7 +391,7 @@ def cpu_baseline_onset(samples, n, hop, sr, n_streams):
         cores = max(1, min(16, len(os.sched_getaffinity(0))))
     except Exception:
         pass
-    p = ox.default_params(fft_len=2 * hop)
+    p = ox.default_params(fft_len=nfft, hop=hop)
 
     def one(row):
         flux, _ = ox.onset_stft(row, sr, p)

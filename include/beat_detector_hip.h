@@ -262,13 +262,13 @@ int bd_synth_fill_host(int16_t *samples, uint64_t n_streams, uint64_t n_samples,
  * 90 Hz of an unwindowed 1024-sample ring and compares their maximum with a
  * constant (src/strategies/spectrum.rs:82-92).  These entry points are the
  * windowed, hop-based version of that idea: Hann STFT (1024 or 2048 points,
- * hop = half), energy of the band up to band_max_hz, spectral flux, onsets by
+ * hop = half or a quarter of the length), energy of the band up to band_max_hz, spectral flux, onsets by
  * adaptive-threshold peak picking.  Results are defined by the CPU definition
  * that the tests hold (same f32 operation order: bit-identical), not by the
  * reference.  All pointers are device pointers; calls only enqueue. */
 typedef struct bd_onset_params {
     uint32_t fft_len;      /* 1024 or 2048 */
-    uint32_t hop;          /* fft_len / 2 */
+    uint32_t hop;          /* fft_len / 2 (default) or fft_len / 4 */
     uint32_t window;       /* 0 rectangular, 1 periodic Hann */
     float    band_max_hz;  /* band energy over bins with k * fs / fft_len <= band_max_hz */
     uint32_t mean_frames;  /* W: threshold follows the mean of flux[j-W .. j+W] */

@@ -185,7 +185,7 @@ int bdo_onset_stft(const int16_t *samples, size_t n_samples, uint32_t sampling_r
                    const bdo_onset_params *p, float *flux, float *band_energy)
 {
     const uint32_t n = p->fft_len, m = n / 2;
-    if ((n != 1024 && n != 2048) || p->hop != n / 2) return -1;
+    if ((n != 1024 && n != 2048) || (p->hop != n / 2 && p->hop != n / 4)) return -1;
     const size_t frames = bdo_onset_frames(n_samples, n, p->hop);
     float *prev = (float *)calloc(m + 1, sizeof(float)), *cur = (float *)malloc((m + 1) * sizeof(float));
     float *term = (float *)malloc((m + 1) * sizeof(float));

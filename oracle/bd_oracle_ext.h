@@ -1,6 +1,6 @@
 /*
  * CPU definition of the "extension" onset analysis: Hann-windowed STFT (1024 or
- * 2048 points, hop = half the length), low-band energy, spectral flux and
+ * 2048 points, hop = half or a quarter of the length), low-band energy, spectral flux and
  * adaptive-threshold peak picking.
  *
  * TEST INFRASTRUCTURE ONLY (same rules as bd_oracle.h).

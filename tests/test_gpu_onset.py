@@ -41,14 +41,16 @@ def _streams(n_streams, n, seed=0):
 @pytest.mark.parametrize("fft_len", [1024, 2048])
 @pytest.mark.parametrize("window", [1, 0])
 @pytest.mark.parametrize("n", [2048 * 70 + 13, 2048 * 3, 2048])
-def test_flux_and_band_energy_bit_exact(bd, oracle_ext, fft_len, window, n):
+@pytest.mark.parametrize("hop_div", [2, 4])
+def test_flux_and_band_energy_bit_exact(bd, oracle_ext, fft_len, window, n, hop_div):
     rows = _streams(9, n, seed=fft_len + window)
     dev, host = _aligned_rows(rows)
-    p = bd.OnsetParams.default(fft_len=fft_len, window=window)
-    op = oracle_ext.default_params(fft_len=fft_len, window=window)
+    hop = fft_len // hop_div
+    p = bd.OnsetParams.default(fft_len=fft_len, hop=hop, window=window)
+    op = oracle_ext.default_params(fft_len=fft_len, hop=hop, window=window)
     flux, band = bd.onset_stft(SR, dev, n_samples=n, params=p)
     flux, band = flux.cpu().numpy(), band.cpu().numpy()
-    nf = oracle_ext.frames(n, fft_len, fft_len // 2)
+    nf = oracle_ext.frames(n, fft_len, hop)
     assert flux.shape == (9, nf)
     for s in range(9):
         want_flux, want_band = oracle_ext.onset_stft(host[s, :n], SR, op)
@@ -68,7 +70,7 @@ def test_short_and_empty_inputs(bd, oracle_ext):
     with pytest.raises(bd.BeatDetectorError):
         bd.onset_stft(SR, dev, params=bd.OnsetParams.default(fft_len=4096))
     with pytest.raises(bd.BeatDetectorError):
-        bd.onset_stft(SR, dev, params=bd.OnsetParams.default(fft_len=2048, hop=512))
+        bd.onset_stft(SR, dev, params=bd.OnsetParams.default(fft_len=2048, hop=256))
 
 
 @pytest.mark.parametrize("fft_len", [1024, 2048])
@@ -76,7 +78,8 @@ def test_onsets_match_definition(bd, oracle_ext, fft_len):
     n = SR * 12 + 77
     rows = _streams(13, n, seed=7)
     dev, host = _aligned_rows(rows)
-    for kw in (dict(), dict(mean_frames=3, max_frames=1, delta=1000.0, lambda_=1.2, min_gap_ms=250),
+    for kw in (dict(), dict(hop=fft_len // 4), dict(hop=fft_len // 4, use_median=1, min_gap_ms=120),
+               dict(mean_frames=3, max_frames=1, delta=1000.0, lambda_=1.2, min_gap_ms=250),
                dict(mean_frames=0, max_frames=0, delta=0.0, lambda_=0.5, min_gap_ms=0),
                dict(use_median=1), dict(use_median=1, mean_frames=32, max_frames=2, lambda_=2.0, min_gap_ms=50)):
         p = bd.OnsetParams.default(fft_len=fft_len, **kw)
