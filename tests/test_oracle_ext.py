@@ -110,3 +110,22 @@ def test_clicks_are_found(oracle_ext):
     gaps = np.diff(ms.astype(np.int64))
     # frame 0 is compared with silence, so its flux is its whole spectrum: skip the first gap
     assert np.all(np.abs(gaps[1:] - 500) <= 47)  # one hop is 23 ms
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_quarter_hop_contains_the_half_hop_frames(oracle_ext, n):
+    """hop = N / 4 adds a frame between every two of hop = N / 2: the band energy of its even frames
+    is that of the half-hop analysis bit for bit (a frame's energy depends on the frame alone), the
+    frame count and time stamps follow the hop, and other hops are refused."""
+    x = click_track(44100 * 2 + 17, 5)
+    half = oracle_ext.default_params(fft_len=n)
+    quarter = oracle_ext.default_params(fft_len=n, hop=n // 4)
+    _, band_h = oracle_ext.onset_stft(x, 44100, half)
+    flux_q, band_q = oracle_ext.onset_stft(x, 44100, quarter)
+    assert len(band_q) == oracle_ext.frames(len(x), n, n // 4) == (len(x) - n) // (n // 4) + 1
+    assert np.array_equal(band_q[::2][:len(band_h)].view(np.uint32), band_h.view(np.uint32))
+    assert (flux_q >= 0).all() and flux_q.max() > 0
+    _, frame, ms = oracle_ext.onset_pick(flux_q, 44100, quarter)
+    assert all(m == ((int(f) * (n // 4) + n // 2) * 1000) // 44100 for f, m in zip(frame, ms))
+    with pytest.raises(Exception):
+        oracle_ext.onset_stft(x, 44100, oracle_ext.default_params(fft_len=n, hop=n // 8))
