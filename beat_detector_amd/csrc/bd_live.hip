@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 static __device__ const float bd_cos1024[1024] = {
 #include "bd_cos1024.inc"
@@ -361,6 +362,7 @@ struct bd_live {
     bd_plan        plan;
     int            device = 0;
     uint32_t       n_streams = 0, max_len = 0, depth = 0;
+    bool           zero_copy = true;     // kernels work on the pinned buffers directly
     hipStream_t    stream = nullptr;
     hipStream_t    cap_stream = nullptr; // graph capture only
     int16_t       *d_ring = nullptr;
@@ -481,6 +483,8 @@ extern "C" int bd_live_create(int kind, uint32_t sampling_rate, const bd_params 
     if (!L) { bd_set_error("out of host memory"); return BD_ERR_HIP; }
     L->plan = plan; L->device = device; L->n_streams = n_streams; L->max_len = max_callback_len;
     L->depth = depth ? (depth > 64 ? 64 : depth) : 4;
+    const char *zc = getenv("BD_LIVE_ZERO_COPY");
+    L->zero_copy = !(zc && zc[0] == '0');
     if (device != prev) BD_HIP(hipSetDevice(device));
     s = bd_live_init(L);
     if (device != prev) (void)hipSetDevice(prev);
@@ -510,21 +514,33 @@ static int bd_live_build_graph(bd_live *L, bd_live_slot &s, uint32_t n, int form
     const size_t M = L->n_streams;
     const size_t elem = format == BD_FMT_F32 ? 4 : 2;
     hipGraph_t graph = nullptr;
+    // Zero-copy tick (default): the kernels read the pinned staging buffer and write the pinned result
+    // buffer through their device addresses, so a tick is one kernel node (two with a format
+    // conversion) instead of copy + kernel + copy.  BD_LIVE_ZERO_COPY=0 keeps the copies.
+    const void *raw = s.d_raw;
+    bd_live_result *res = s.d_res;
+    if (L->zero_copy) {
+        void *dp_in = nullptr, *dp_res = nullptr;
+        BD_HIP(hipHostGetDevicePointer(&dp_in, s.h_in, 0));
+        BD_HIP(hipHostGetDevicePointer(&dp_res, s.h_res, 0));
+        raw = dp_in; res = (bd_live_result *)dp_res;
+    }
     BD_HIP(hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeRelaxed));
-    hipError_t e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->cap_stream);
-    const int16_t *in16 = (const int16_t *)s.d_raw;
+    hipError_t e = hipSuccess;
+    if (!L->zero_copy) e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->cap_stream);
+    const int16_t *in16 = (const int16_t *)raw;
     if (e == hipSuccess && format != BD_FMT_I16) {
         const uint64_t total = (uint64_t)M * n;
         hipLaunchKernelGGL(bd_live_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L->cap_stream,
-                           (const void *)s.d_raw, s.d_i16, total, format);
+                           raw, s.d_i16, total, format);
         in16 = s.d_i16;
     }
     if (e == hipSuccess) {
         bd_live_args a;
         a.in = in16; a.in_stride = n; a.n = n;
-        a.ring = L->d_ring; a.state = L->d_state; a.result = s.d_res; a.plan = L->plan;
+        a.ring = L->d_ring; a.state = L->d_state; a.result = res; a.plan = L->plan;
         hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->cap_stream, a);
-        e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->cap_stream);
+        if (!L->zero_copy) e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->cap_stream);
     }
     hipError_t e2 = hipStreamEndCapture(L->cap_stream, &graph);
     if (e != hipSuccess || e2 != hipSuccess) {
