@@ -13,8 +13,10 @@ for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
     x = bd.synth_fill_host(M, L * 64, seed=11)
     live = bd.Live(kind, sr, M, max_callback_len=L, depth=4)
     lat = []
+    # the callbacks of a tick as the source delivers them: one contiguous [streams, L] block
+    wins = [np.ascontiguousarray(x[:, i * L:(i + 1) * L]) for i in range(64)]
     for t in range(ticks + 20):
-        w = x[:, (t % 64) * L:(t % 64 + 1) * L]
+        w = wins[t % 64]
         t0 = time.perf_counter()
         tick = live.submit(w)
         live.poll(tick)
