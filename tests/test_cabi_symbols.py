@@ -36,3 +36,24 @@ def test_python_binding_covers_the_header(bd):
 def test_library_has_gfx950_code_object(bd):
     data = open(bd.lib_path(), "rb").read()
     assert b"gfx950" in data
+
+
+def test_rust_bindings_name_only_declared_symbols(bd):
+    """hip/src/lib.rs (source only: no Rust toolchain here) must bind symbols the header declares
+    and the library exports, and its #[repr(C)] parameter structs must list the header's fields in order."""
+    import os, re
+    from beat_detector_amd.api import EXPORTED_SYMBOLS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = open(os.path.join(root, "hip", "src", "lib.rs")).read()
+    header = open(os.path.join(root, "include", "beat_detector_hip.h")).read()
+    bound = set(re.findall(r"pub fn (bd_\w+)\s*\(", rs))
+    assert len(bound) >= 15
+    for name in bound:
+        assert re.search(r"\b%s\s*\(" % name, header), name
+        assert name in EXPORTED_SYMBOLS, name
+    for struct in ("bd_params", "bd_onset_params", "bd_biquad_params"):
+        rs_fields = re.findall(r"pub (\w+):", re.search(r"pub struct %s \{(.*?)\}" % struct, rs, re.S).group(1))
+        h_body = re.search(r"typedef struct %s\s*\{(.*?)\}\s*%s;" % (struct, struct), header, re.S).group(1)
+        h_body = re.sub(r"/\*.*?\*/", "", h_body, flags=re.S)
+        h_fields = re.findall(r"(\w+)\s*;", h_body)
+        assert [f.rstrip("_") for f in rs_fields] == h_fields, struct
