@@ -84,3 +84,38 @@ def test_extension_batches(bd, oracle_ext):
         assert res.onsets(s) == list(zip(frame.tolist(), ms.tolist())), s
     del res, buf
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("kind_name,L,sr,kernel", [
+    ("Spectrum", 441, SR, "bd_spectrum_window_kernel"), ("Spectrum", 480, SR, "bd_spectrum_granule_kernel"),
+    ("Spectrum", 512, 16000, "bd_spectrum_granule_kernel"), ("Spectrum", 441, 22050, "bd_spectrum_window_kernel"),
+    ("LPF", 441, SR, "bd_lpf_window_kernel"), ("LPF", 1000, SR, "bd_lpf_window_kernel")])
+def test_other_lengths_and_rates_at_4096_streams(bd, oracle, kind_name, L, sr, kernel):
+    """The kernels behind callback lengths off the 64-sample grid and behind low sampling rates, on a
+    batch large enough to fill the GPU many times over; sampled streams against the oracle."""
+    import torch
+    n = SR * 60
+    buf = torch.empty((4096, (n + 63) & ~63), dtype=torch.int16, device="cuda")
+    bd.synth_fill(buf, n_samples=n, seed=77, sampling_rate=sr)
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    res = bd.analyze_batch(kind, sr, buf, L, n_samples=n)
+    torch.cuda.synchronize()
+    assert bd.last_kernel_name() == kernel
+    p = oracle.default_params()
+    div = oracle.bin_range(sr, p)[0]
+    for s in _sample(4096):
+        row = buf[s, :n].cpu().numpy()
+        v, c, beats = oracle.run_stream(okind, sr, row, L, full=True)
+        got_v, got_c = res.values[s].cpu().numpy(), res.flags[s].cpu().numpy()
+        if kind_name == "LPF":
+            assert np.array_equal(got_v, v) and np.array_equal(got_c, c), s
+            assert res.beats(s) == beats, s
+        else:
+            assert (np.abs(got_v - v) <= util.value_tolerance(v, 32768, div)).all(), s
+            adjacent = util.threshold_adjacent(v, 2.1e6)
+            assert ((got_c == c) | adjacent).all(), s
+            if not adjacent.any():
+                assert res.beats(s) == beats, s
+    del res, buf
+    torch.cuda.empty_cache()
