@@ -620,6 +620,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     const uint32_t gran = bd_spectrum_granule_size(callback_len);
     if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) &&
         !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
+        // (granules of 63 samples for 63 q: 441, 882 below the window kernel's HBM-bound range)
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
     // everything else with at most 12 kept bins: the window kernel; the callbacks whose ring starts

@@ -254,6 +254,228 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
     }
 }
 
+// ---- granules of 63 samples -------------------------------------------------
+// Callback lengths 63 q (441 = 10 ms at 44.1 kHz, 882, ...) end on a grid of 63-sample granules.
+// The ring of a callback is the last 16 granules (1008 samples) plus the last 16 samples of the
+// granule before them.  Every lane sums its granule in two parts, A over samples 0 .. 46 and B over
+// samples 47 .. 62 (P = A + B), and
+//     X_k(e) = B_k(e - 16) + w^{63 k} Q_k(e),   Q = the four doubling levels over P with offsets 63 * 2^j
+// up to a rotation of the whole ring, which no magnitude depends on.  The callback's own samples are
+// its last q granules, so the amplitude gate is the same sliding maximum as for the other granule
+// sizes.  A step is 64 granules = 4032 samples = 504 16-byte units, copied to LDS as they lie in
+// memory; lane l reads its 63 samples from byte 126 l on.
+struct bd_g63_part { float re[2], im[2]; int dc, ny; };
+
+// Samples FROM .. TO - 1 of the lane's granule.  (Written sample by sample: the compiler turns the
+// reads into 16-byte LDS reads at the row's 2-byte-aligned address; a version on explicit dwords
+// with packed integer sums was slower.)
+template <int NK, bool NYQ, int FROM, int TO>
+__device__ __forceinline__ void bd_g63_sum(const int16_t *row, bd_g63_part &p, float &amax)
+{
+#pragma unroll
+    for (int k = 0; k < 2; k++) { p.re[k] = 0.f; p.im[k] = 0.f; }
+    p.dc = 0; p.ny = 0;
+#pragma unroll
+    for (int n = FROM; n < TO; n++) {
+        const int v = row[n];
+        const float x = (float)v;
+        p.dc += v;
+        if (NYQ) p.ny += (n & 1) ? -v : v;
+        amax = fmaxf(amax, fabsf(x));
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            p.re[k] = __builtin_fmaf(x, BD_GR_C[k][n], p.re[k]);
+            p.im[k] = __builtin_fmaf(x, BD_GR_S[k][n], p.im[k]);
+        }
+    }
+}
+
+template <int NK, bool NYQ>
+__global__ __launch_bounds__(256) void bd_spectrum_g63_kernel(bd_gr_args a)
+{
+    constexpr int G = 63, UNITS = 504;          // samples per granule, 16-byte units per step
+    __shared__ __attribute__((aligned(16))) uint4 tile_all[4][UNITS];
+    __shared__ float out_v[4][128];
+    __shared__ uint8_t out_f[4][128];
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    if (task >= a.n_tasks) return;
+    const uint64_t s = task / a.runs_per_stream;
+    const uint64_t r = task - s * a.runs_per_stream;
+    uint4 *tile = tile_all[wave];
+    const int16_t *sp = a.samples + s * a.stride;
+    const uint64_t n_steps = (a.n_gran + 63) / 64;
+    const uint64_t st0 = r * a.steps_per_run;
+    const uint64_t st1 = st0 + a.steps_per_run < n_steps ? st0 + a.steps_per_run : n_steps;
+    const uint64_t st_first = st0 > 0 ? st0 - 1 : 0;   // replayed step: fills the "previous step" values
+    const uint64_t n_valid = a.n_gran * G;              // samples that belong to callbacks
+    const uint32_t m = a.m;
+    const int lg = 31 - __builtin_clz(m);
+    const int tail = (int)m - (1 << lg);
+
+    const bool mis = a.misaligned != 0;
+    uint4 ld[8];
+    auto load_step = [&](uint64_t st) {
+        const uint64_t first = st * (64 * G);           // first sample of the step
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int u = j * 64 + lane;
+            const uint64_t at = first + (uint64_t)u * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (u < UNITS && at + 8 <= n_valid) {
+                v = bd_gr_load16(sp + at, mis);
+            } else if (u < UNITS && at < n_valid) {      // the unit that holds the last samples: one by one
+                unsigned w[4] = {0, 0, 0, 0};
+                for (uint64_t e = 0; e < n_valid - at; e++) w[e >> 1] |= (unsigned)(uint16_t)sp[at + e] << (16 * (e & 1));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            ld[j] = v;
+        }
+    };
+    load_step(st_first);
+    const int16_t *row = reinterpret_cast<const int16_t *>(tile) + G * lane;
+
+    // values of the previous step, per doubling level (zero = silence before the stream)
+    float p_re[4][NK > 0 ? NK : 1], p_im[4][NK > 0 ? NK : 1], p_amax[6];
+    int p_dc[4], p_ny[4];
+    float pb_re[NK > 0 ? NK : 1], pb_im[NK > 0 ? NK : 1];   // B of the previous step
+    int pb_dc = 0, pb_ny = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        p_dc[j] = 0; p_ny[j] = 0;
+#pragma unroll
+        for (int k = 0; k < (NK > 0 ? NK : 1); k++) { p_re[j][k] = 0.f; p_im[j][k] = 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < (NK > 0 ? NK : 1); k++) { pb_re[k] = 0.f; pb_im[k] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 6; j++) p_amax[j] = 0.f;
+    float p_amax_top = 0.f;
+
+    uint32_t pend = 0;
+    uint64_t cb_base = (st0 * 64) / m;
+
+    for (uint64_t st = st_first; st < st1; st++) {
+        bd_gr_sync();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (j * 64 + lane < UNITS) tile[j * 64 + lane] = ld[j];
+        bd_gr_sync();
+        // the lane's granule in two parts; the alternating sum takes the sign of the sample's place
+        // in the stream (granule g starts at an odd sample when g is odd)
+        bd_g63_part A, B;
+        float amax = 0.f;
+        bd_g63_sum<NK, NYQ, 0, 47>(row, A, amax);
+        bd_g63_sum<NK, NYQ, 47, 63>(row, B, amax);
+        if (st + 1 < st1) load_step(st + 1);
+        if (NYQ && (lane & 1)) { A.ny = -A.ny; B.ny = -B.ny; }
+        float re[NK > 0 ? NK : 1], im[NK > 0 ? NK : 1];
+        int dc = A.dc + B.dc, ny = A.ny + B.ny;
+#pragma unroll
+        for (int k = 0; k < NK; k++) { re[k] = A.re[k] + B.re[k]; im[k] = A.im[k] + B.im[k]; }
+        // B of the granule 16 before this one
+        float b_re[NK > 0 ? NK : 1], b_im[NK > 0 ? NK : 1];
+        const int b_dc = bd_gr_back(B.dc, pb_dc, lane, 16);
+        const int b_ny = NYQ ? bd_gr_back(B.ny, pb_ny, lane, 16) : 0;
+        pb_dc = B.dc; pb_ny = B.ny;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            b_re[k] = bd_gr_back(B.re[k], pb_re[k], lane, 16);
+            b_im[k] = bd_gr_back(B.im[k], pb_im[k], lane, 16);
+            pb_re[k] = B.re[k]; pb_im[k] = B.im[k];
+        }
+        // doubling levels: 1 -> 16 granules
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int d = 1 << j;
+            const int q_dc = bd_gr_back(dc, p_dc[j], lane, d);
+            p_dc[j] = dc;
+            dc = q_dc + dc;
+            if (NYQ) {
+                const int q_ny = bd_gr_back(ny, p_ny[j], lane, d);
+                p_ny[j] = ny;
+                ny = q_ny + ny;
+            }
+#pragma unroll
+            for (int k = 0; k < NK; k++) {
+                const float q_re = bd_gr_back(re[k], p_re[j][k], lane, d), q_im = bd_gr_back(im[k], p_im[j][k], lane, d);
+                p_re[j][k] = re[k]; p_im[j][k] = im[k];
+                const float c = BD_G63L_C[k][j], sn = BD_G63L_S[k][j];
+                const float nr = q_re + (c * re[k] - sn * im[k]);
+                const float ni = q_im + (c * im[k] + sn * re[k]);
+                re[k] = nr; im[k] = ni;
+            }
+        }
+        // the 16 samples before the 16 granules
+        dc += b_dc; ny += b_ny;
+#pragma unroll
+        for (int k = 0; k < NK; k++) {
+            const float c = BD_G63L_C[k][0], sn = BD_G63L_S[k][0];
+            const float nr = b_re[k] + (c * re[k] - sn * im[k]);
+            const float ni = b_im[k] + (c * im[k] + sn * re[k]);
+            re[k] = nr; im[k] = ni;
+        }
+        // amplitude gate: maximum over the callback's own m granules
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            if (j < lg) {
+                const float b = bd_gr_back(amax, p_amax[j], lane, 1 << j);
+                p_amax[j] = amax;
+                amax = fmaxf(amax, b);
+            }
+        }
+        float gate_max = amax;
+        if (tail > 0) gate_max = fmaxf(amax, bd_gr_back(amax, p_amax_top, lane, tail));
+        p_amax_top = amax;
+
+        const uint64_t g = st * 64 + (uint64_t)lane;
+        const bool ends = st >= st0 && g < a.n_gran && (g + 1) % m == 0;
+        float value = 0.f;
+        bool flag = false;
+        {
+            const float x_dc = (float)dc;
+            float m0 = fabsf(x_dc);
+            if (NYQ) {
+                const float x_ny = (float)ny;
+                m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
+            }
+            float best = a.include_dc ? m0 : 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; k++) best = fmaxf(best, sqrtf(re[k] * re[k] + im[k] * im[k]));
+            value = (a.divisor == 0.f) ? best : best / a.divisor;
+            flag = fminf(gate_max, 32767.f) >= (float)a.min_amp && value > a.threshold;
+        }
+        const unsigned long long mask = __ballot(ends);
+        if (ends) {
+            const uint32_t slot = pend + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            out_v[wave][slot] = value;
+            out_f[wave][slot] = flag ? 1 : 0;
+        }
+        pend += (uint32_t)__builtin_popcountll(mask);
+        if (pend >= 64 || st + 1 == st1) {
+            bd_gr_sync();
+            const uint64_t o0 = s * a.out_stride + cb_base;
+            if (a.values) {
+                __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values + o0, pend * 4u);
+                for (unsigned i = lane; i < pend; i += 64) bd_store_stream_f32(rv, i * 4u, out_v[wave][i]);
+            }
+            __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, pend);
+            for (unsigned i = lane; i < pend; i += 64) bd_store_stream_u8(rf, i, out_f[wave][i]);
+            cb_base += pend;
+            pend = 0;
+        }
+    }
+}
+
+template <int NK>
+static void bd_g63_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+{
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_g63_kernel<NK, true>), dim3(grid), dim3(256), 0, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_g63_kernel<NK, false>), dim3(grid), dim3(256), 0, st, a);
+}
+
 template <int NK, int G>
 static void bd_gr_launch2(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
 {
@@ -277,6 +499,8 @@ uint32_t bd_spectrum_granule_size(uint32_t callback_len)
     if (callback_len % 64 == 0) return callback_len <= 4096 ? 64 : 0;
     if (callback_len % 32 == 0) return callback_len <= 512 ? 32 : 0;
     if (callback_len % 16 == 0) return callback_len <= 256 ? 16 : 0;
+    // 63 q: 441 (10 ms at 44.1 kHz) and its kin, while the window kernel is not yet bound by HBM
+    if (callback_len % 63 == 0) return callback_len <= 819 ? 63 : 0;
     return 0;
 }
 
@@ -284,7 +508,7 @@ uint32_t bd_spectrum_granule_size(uint32_t callback_len)
 // every bin live in registers: fewer bins where there are more levels).
 int bd_spectrum_granule_max_bins(uint32_t gran)
 {
-    return gran == 64 ? BD_GR_MAX_BINS : gran == 32 ? 8 : gran == 16 ? 5 : -1;
+    return gran == 64 ? BD_GR_MAX_BINS : gran == 32 ? 8 : gran == 16 ? 5 : gran == 63 ? 2 : -1;
 }
 
 // Returns BD_OK after enqueueing, or a negative status; the caller has checked that
@@ -318,6 +542,13 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     const unsigned grid = (unsigned)grid64;
     a.nk_keep = (uint32_t)plan.last_bin;
     if (plan.last_bin > bd_spectrum_granule_max_bins(gran)) { bd_set_error("too many bins for this granule size"); return BD_ERR_UNSUPPORTED; }
+    if (gran == 63) {
+        if (plan.last_bin == 0) bd_g63_launch<0>(nyq, a, grid, st);
+        else if (plan.last_bin == 1) bd_g63_launch<1>(nyq, a, grid, st);
+        else bd_g63_launch<2>(nyq, a, grid, st);
+        bd_set_last_kernel("bd_spectrum_g63_kernel");
+        return bd_check_hip(hipGetLastError(), "launch bd_spectrum_g63_kernel");
+    }
     if (plan.last_bin == 0) bd_gr_launch<0>(gran, nyq, a, grid, st);
     else if (plan.last_bin == 1) bd_gr_launch<1>(gran, nyq, a, grid, st);
     else if (plan.last_bin == 2) bd_gr_launch<2>(gran, nyq, a, grid, st);

@@ -79,7 +79,7 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 100, 317, 441, 529, 700, 720, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
+@pytest.mark.parametrize("L", [1, 7, 100, 317, 450, 529, 700, 720, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
 def test_spectrum_window_callback_lengths(bd, oracle, L):
     """Callback lengths that are not multiples of 64 (or lie above 4096): the window kernel, with the
     callbacks whose ring starts before the stream on the generic kernel; streams of one callback, of a
@@ -96,6 +96,31 @@ def test_spectrum_window_callback_lengths(bd, oracle, L):
     for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
                dict(spectrum_max_hz=50.0), dict(spectrum_max_hz=10.0)):
         _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+
+
+@pytest.mark.parametrize("L", [63, 126, 441, 504, 693, 819])
+def test_spectrum_granules_of_63_samples(bd, oracle, L):
+    """Callback lengths 63 q up to 819 (441 = 10 ms at 44.1 kHz): granules of 63 samples; short streams,
+    partial steps, several runs, rows that are only 2-byte aligned, the unpinned choices."""
+    import torch
+    for n, streams in ((40000, 3), (4032 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4032 * 40 + 5, 1), (1024 + L, 2)):
+        x = _synth(bd, streams, n, first=3)
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+        if n // L > 0:
+            assert bd.last_kernel_name() == "bd_spectrum_g63_kernel"
+    x = _synth(bd, 2, 50000, first=9)
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
+               dict(spectrum_max_hz=50.0), dict(spectrum_max_hz=10.0)):
+        _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+    n = 30011
+    x = _synth(bd, 3, n, first=5)
+    flat = torch.zeros(1 + 3 * (n + 3), dtype=torch.int16, device="cuda")
+    view = flat[1:].view(3, n + 3)
+    view[:, :n] = torch.from_numpy(x).cuda()
+    res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, view, L, n_samples=n)
+    ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_SPECTRUM, SR, x, L)
+    assert (np.abs(res.values.cpu().numpy() - ref_v) <= util.value_tolerance(ref_v, 32768, 3)).all()
+    np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
 
 
 @pytest.mark.parametrize("L", [7, 441, 1000, 1500])
@@ -156,7 +181,7 @@ def test_spectrum_more_than_three_bins(bd, oracle, sr):
     for L in (512, 1024, 256, 2048, 64, 4096):
         _compare(bd, oracle, "Spectrum", sr, x, L)
         assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
-    for L in (441, 1000, 5000, 800):       # off the grids of the granule kernel: the window kernel
+    for L in (450, 1000, 5000, 800):       # off the grids of the granule kernel: the window kernel
         _compare(bd, oracle, "Spectrum", sr, x, L)
         assert bd.last_kernel_name() == "bd_spectrum_window_kernel"
     for L, max_bins in ((160, 8), (480, 8), (96, 8), (240, 5), (48, 5)):   # granules of 32 / 16 samples
@@ -164,7 +189,7 @@ def test_spectrum_more_than_three_bins(bd, oracle, sr):
         last_bin = oracle.bin_range(sr, oracle.default_params())[2]
         assert bd.last_kernel_name() == ("bd_spectrum_granule_kernel" if last_bin <= max_bins else "bd_spectrum_window_kernel")
     for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_max_hz=60.0)):
-        _compare(bd, oracle, "Spectrum", sr, x, 441, bd.Params.default(**kw), oracle.default_params(**kw))
+        _compare(bd, oracle, "Spectrum", sr, x, 450, bd.Params.default(**kw), oracle.default_params(**kw))
     for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
                dict(spectrum_max_hz=60.0)):
         _compare(bd, oracle, "Spectrum", sr, x, 512, bd.Params.default(**kw), oracle.default_params(**kw))
@@ -438,7 +463,7 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
     view[:, :n] = torch.from_numpy(x).cuda()
     assert view.data_ptr() % 4 == 2
     for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
-                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_window_kernel"),
+                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_g63_kernel"),
                                  ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
         kind = bd.StrategyKind[kind_name]
         okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
