@@ -291,7 +291,7 @@ __device__ __forceinline__ void bd_g63_sum(const int16_t *row, bd_g63_part &p, f
 }
 
 template <int NK, bool NYQ>
-__global__ __launch_bounds__(256) void bd_spectrum_g63_kernel(bd_gr_args a)
+__global__ __launch_bounds__(256, 3) void bd_spectrum_g63_kernel(bd_gr_args a)
 {
     constexpr int G = 63, UNITS = 504;          // samples per granule, 16-byte units per step
     __shared__ __attribute__((aligned(16))) uint4 tile_all[4][UNITS];
