@@ -62,25 +62,31 @@ __device__ __forceinline__ void bd_gr_absmax(float &m, float a, float b)
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
 }
 
-// value of lane (l - d) of this step, or of lane (l - d + 64) of the previous step
-__device__ __forceinline__ float bd_gr_back(float cur, float prev, int lane, int d)
+// value of lane (l - d) of this step, or of lane (l - d + 64) of the previous step.  The lanes whose
+// value wraps around (the last d) hand over the previous step's value, so that one rotation of the
+// wavefront by d delivers both: a DPP wave rotation for d = 1, 2 (no LDS traffic; `d` is a constant
+// there after unrolling), ds_bpermute otherwise.
+__device__ __forceinline__ int bd_gr_rot1(int v)
 {
-    const int src = (lane - d) & 63;
-    const float c = __shfl(cur, src, 64), p = __shfl(prev, src, 64);
-    return lane >= d ? c : p;
+    return __builtin_amdgcn_update_dpp(0, v, 0x13C /* wave_ror:1 */, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int bd_gr_back(int cur, int prev, int lane, int d)
 {
-    const int src = (lane - d) & 63;
-    const int c = __shfl(cur, src, 64), p = __shfl(prev, src, 64);
-    return lane >= d ? c : p;
+    const int send = lane >= 64 - d ? prev : cur;
+    if (__builtin_constant_p(d) && d == 1) return bd_gr_rot1(send);
+    if (__builtin_constant_p(d) && d == 2) return bd_gr_rot1(bd_gr_rot1(send));
+    return __shfl(send, (lane - d) & 63, 64);
+}
+__device__ __forceinline__ float bd_gr_back(float cur, float prev, int lane, int d)
+{
+    return __builtin_bit_cast(float, bd_gr_back(__builtin_bit_cast(int, cur), __builtin_bit_cast(int, prev), lane, d));
 }
 
 // G: samples per granule (64, 32 or 16).  NK: non-DC bins evaluated: 0 .. 2 at the usual sampling
 // rates; 3, 4, 5, 8 or 11 where the band up to 90 Hz holds more bins (sampling rates down to 8 kHz;
 // at most 8 with G = 32, 5 with G = 16), of which the first nk_keep count.
 template <int NK, bool NYQ, int G>
-__global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
+__device__ __forceinline__ void bd_spectrum_granule_body(const bd_gr_args &a)
 {
     constexpr int DW = G / 2;                 // dwords of samples per granule
     constexpr int U4 = G / 8;                 // 16-byte units per granule
@@ -252,6 +258,19 @@ __global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
             pend = 0;
         }
     }
+}
+
+template <int NK, bool NYQ, int G>
+__global__ __launch_bounds__(256) void bd_spectrum_granule_kernel(bd_gr_args a)
+{
+    bd_spectrum_granule_body<NK, NYQ, G>(a);
+}
+// eight and more bins: the doubling levels of every bin fill the register file; asking for two waves
+// per SIMD keeps the compiler from settling just above that limit
+template <int NK, bool NYQ, int G>
+__global__ __launch_bounds__(256, 2) void bd_spectrum_granule_kernel_w2(bd_gr_args a)
+{
+    bd_spectrum_granule_body<NK, NYQ, G>(a);
 }
 
 // ---- granules of 63 samples -------------------------------------------------
@@ -479,6 +498,11 @@ static void bd_g63_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStrea
 template <int NK, int G>
 static void bd_gr_launch2(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
 {
+    if (NK >= 8) {
+        if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel_w2<NK, true, G>), dim3(grid), dim3(256), 0, st, a);
+        else     hipLaunchKernelGGL((bd_spectrum_granule_kernel_w2<NK, false, G>), dim3(grid), dim3(256), 0, st, a);
+        return;
+    }
     if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, true, G>), dim3(grid), dim3(256), 0, st, a);
     else     hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, false, G>), dim3(grid), dim3(256), 0, st, a);
 }

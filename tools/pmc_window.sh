@@ -30,10 +30,10 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         a = acc[row["Kernel_Name"][:40]][row["Counter_Name"]]
         a[0] += float(row["Counter_Value"]); a[1] += 1
 for k, cs in acc.items():
-    if "window" in k:
+    if "spectrum" in k:
         print(k, {c: round(v[0] / v[1]) for c, v in sorted(cs.items())})
 for f in glob.glob(sys.argv[1] + "/trace/**/*kernel_stats.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "window" in row["Name"]:
+        if "spectrum" in row["Name"]:
             print(row["Name"][:50], row["Calls"], row["AverageNs"])
 PY
