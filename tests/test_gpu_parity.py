@@ -497,7 +497,7 @@ def test_ragged_batch(bd, oracle, kind_name):
     buf = torch.zeros((len(lens), (nmax + 63) & ~63), dtype=torch.int16, device="cuda")
     buf[:, :nmax] = torch.from_numpy(host).cuda()
     lengths = torch.tensor(lens, dtype=torch.int64, device="cuda")
-    for L in (512, 1024, 256, 441):
+    for L in (512, 1024, 256, 441, 450, 480):
         res = bd.analyze_batch_ragged(kind, SR, buf, lengths, L)
         torch.cuda.synchronize()
         for i, n in enumerate(lens):
