@@ -564,3 +564,45 @@ def test_row_layouts(bd, oracle):
         torch.cuda.synchronize()
         _, ref_c, _ = util.oracle_batch(oracle, okind, SR, x, 1024)
         np.testing.assert_array_equal(flags.cpu().numpy(), ref_c)
+
+
+def test_concurrent_callers_on_their_own_streams(bd, oracle):
+    """Several host threads, each enqueueing batches on a HIP stream of its own (ctypes releases the GIL);
+    also the host-pointer entry from two threads at once.  Every result equals the single-threaded one."""
+    import threading
+    torch = _torch()
+    jobs = [("Spectrum", 512), ("LPF", 1024), ("Spectrum", 441), ("LPF", 441), ("Spectrum", 1000), ("Spectrum", 160)]
+    x = _synth(bd, 6, SR * 4 + 123, first=60)
+    refs = {j: util.oracle_batch(oracle, oracle.KIND_SPECTRUM if j[0] == "Spectrum" else oracle.KIND_LPF, SR, x, j[1]) for j in jobs}
+    dev = torch.zeros((6, (x.shape[1] + 7) & ~7), dtype=torch.int16, device="cuda")
+    dev[:, :x.shape[1]] = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    errors = []
+
+    def device_worker(job):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(5):
+                    res = bd.analyze_batch(bd.StrategyKind[job[0]], SR, dev, job[1], n_samples=x.shape[1], stream=st)
+                st.synchronize()
+            ref_v, ref_c, ref_b = refs[job]
+            np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
+            assert all(res.beats(s) == ref_b[s] for s in range(6))
+        except Exception as e:       # surfaced in the main thread
+            errors.append((job, repr(e)))
+
+    def host_worker(job):
+        try:
+            res = bd.analyze_batch_host(bd.StrategyKind[job[0]], SR, x, job[1])
+            np.testing.assert_array_equal(res.flags, refs[job][1])
+        except Exception as e:
+            errors.append((job, repr(e)))
+
+    threads = [threading.Thread(target=device_worker, args=(j,)) for j in jobs]
+    threads += [threading.Thread(target=host_worker, args=(j,)) for j in jobs[:2]]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
