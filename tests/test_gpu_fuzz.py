@@ -3,6 +3,8 @@ base offsets (rows that are only 2-byte aligned), both strategies and the docume
 variants, each compared with the CPU oracle.  Exercises every kernel the length routing can pick
 (half-block, granule 64 / 32 / 16, window, generic, LPF aligned and line staging) on inputs no
 hand-written case lists."""
+import os
+
 import numpy as np
 import pytest
 
@@ -36,7 +38,7 @@ def _case(rng):
     return kind_name, L, n_streams, n, pad, off, sr
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("BD_FUZZ_SEEDS", "24"))))   # more seeds for a soak run
 def test_random_shapes_against_the_oracle(bd, oracle, seed):
     import torch
     rng = np.random.default_rng(1000 + seed)
