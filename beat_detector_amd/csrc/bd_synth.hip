@@ -94,33 +94,118 @@ extern "C" int bd_synth_fill_host(int16_t *samples, uint64_t n_streams, uint64_t
 }
 
 // ---- ingest converters, src/record.rs:151-166 -------------------------------
-__global__ void bd_u16_to_i16_kernel(const uint16_t *in, int16_t *out, uint64_t n)
+// Streaming element-wise kernels: with 16-byte aligned buffers every thread converts the eight
+// samples of one 16-byte output unit (16-byte non-temporal loads, one 16-byte store) and one more
+// thread the up to seven samples after the last whole unit; other buffers take one sample per thread.
+__device__ __forceinline__ int16_t bd_cvt_u16(uint16_t v)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t x = (int32_t)in[i] - (int32_t)(INT16_MAX / 2); // record.rs:154-155
-    out[i] = (int16_t)(uint16_t)(uint32_t)x;                     // :156 wrapping cast
+    const int32_t x = (int32_t)v - (int32_t)(INT16_MAX / 2);    // record.rs:154-155
+    return (int16_t)(uint16_t)(uint32_t)x;                       // :156 wrapping cast
 }
-
-__global__ void bd_f32_to_i16_kernel(const float *in, int16_t *out, uint64_t n)
+__device__ __forceinline__ int16_t bd_cvt_f32(float v)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float x = in[i] * 32767.0f;                            // record.rs:163
+    const float x = v * 32767.0f;                                // record.rs:163
     // `as i16`: truncate toward zero, saturate, NaN -> 0        // :164
     float t = truncf(x);
     t = (t != t) ? 0.f : fminf(fmaxf(t, -32768.f), 32767.f);
-    out[i] = (int16_t)(int)t;
+    return (int16_t)(int)t;
+}
+// Down-mix of one interleaved stereo frame as the reference's test harness does it
+// (src/lib.rs:310-337: `((l as i32 + r as i32) as f32 / 2.0) as i16`, i.e. the sum halved
+// with truncation toward zero; the sum of two i16 is exact in f32).
+__device__ __forceinline__ int16_t bd_cvt_stereo(int16_t l, int16_t r)
+{
+    return (int16_t)(((int32_t)l + (int32_t)r) / 2); // C division truncates toward zero, like the f32 -> i16 cast
+}
+__device__ __forceinline__ unsigned bd_pack16(int16_t lo, int16_t hi)
+{
+    return (unsigned)(uint16_t)lo | ((unsigned)(uint16_t)hi << 16);
+}
+__device__ __forceinline__ void bd_store_unit(int16_t *out, uint64_t unit, const unsigned (&w)[4])
+{
+    bd_u32x4 v = {w[0], w[1], w[2], w[3]};
+    __builtin_nontemporal_store(v, reinterpret_cast<bd_u32x4 *>(out) + unit);
+}
+
+// VEC: 16-byte aligned buffers
+template <bool VEC>
+__global__ __launch_bounds__(256) void bd_u16_to_i16_kernel(const uint16_t *in, int16_t *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!VEC) { if (i < n) out[i] = bd_cvt_u16(in[i]); return; }
+    const uint64_t units = n / 8;
+    if (i < units) {
+        const uint4 v = bd_load_stream16(reinterpret_cast<const uint4 *>(in) + i);
+        const unsigned s[4] = {v.x, v.y, v.z, v.w};
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = bd_pack16(bd_cvt_u16((uint16_t)(s[q] & 0xffff)), bd_cvt_u16((uint16_t)(s[q] >> 16)));
+        bd_store_unit(out, i, w);
+    } else if (i == units) {
+        for (uint64_t e = units * 8; e < n; e++) out[e] = bd_cvt_u16(in[e]);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bd_f32_to_i16_kernel(const float *in, int16_t *out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!VEC) { if (i < n) out[i] = bd_cvt_f32(in[i]); return; }
+    const uint64_t units = n / 8;
+    if (i < units) {
+        const uint4 a = bd_load_stream16(reinterpret_cast<const uint4 *>(in) + 2 * i);
+        const uint4 b = bd_load_stream16(reinterpret_cast<const uint4 *>(in) + 2 * i + 1);
+        const unsigned s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            w[q] = bd_pack16(bd_cvt_f32(__builtin_bit_cast(float, s[2 * q])), bd_cvt_f32(__builtin_bit_cast(float, s[2 * q + 1])));
+        bd_store_unit(out, i, w);
+    } else if (i == units) {
+        for (uint64_t e = units * 8; e < n; e++) out[e] = bd_cvt_f32(in[e]);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bd_stereo_to_mono_kernel(const int16_t *in, int16_t *out, uint64_t n_frames)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (!VEC) { if (i < n_frames) out[i] = bd_cvt_stereo(in[2 * i], in[2 * i + 1]); return; }
+    const uint64_t units = n_frames / 8;
+    if (i < units) {
+        const uint4 a = bd_load_stream16(reinterpret_cast<const uint4 *>(in) + 2 * i);
+        const uint4 b = bd_load_stream16(reinterpret_cast<const uint4 *>(in) + 2 * i + 1);
+        const unsigned s[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};   // one frame (l, r) per dword
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            w[q] = bd_pack16(bd_cvt_stereo((int16_t)(s[2 * q] & 0xffff), (int16_t)(s[2 * q] >> 16)),
+                             bd_cvt_stereo((int16_t)(s[2 * q + 1] & 0xffff), (int16_t)(s[2 * q + 1] >> 16)));
+        bd_store_unit(out, i, w);
+    } else if (i == units) {
+        for (uint64_t e = units * 8; e < n_frames; e++) out[e] = bd_cvt_stereo(in[2 * e], in[2 * e + 1]);
+    }
+}
+
+// threads of a launch: one per 16-byte unit plus one for the tail, or one per sample
+static bool bd_cvt_grid(const void *in, const void *out, uint64_t n, bool *vec, unsigned *grid)
+{
+    *vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const uint64_t threads = *vec ? n / 8 + 1 : n;
+    const uint64_t grid64 = (threads + 255) / 256;
+    if (grid64 > 0x7fffffffull) { bd_set_error("buffer too large for one launch"); return false; }
+    *grid = (unsigned)grid64;
+    return true;
 }
 
 extern "C" int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, void *hip_stream)
 {
     if ((!in || !out) && n) { bd_set_error("bd_u16_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n == 0) return BD_OK;
-    const uint64_t grid64 = (n + 255) / 256;
-    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bd_u16_to_i16_kernel, dim3((unsigned)grid64), dim3(256), 0,
-                       (hipStream_t)hip_stream, in, out, n);
+    bool vec; unsigned grid;
+    if (!bd_cvt_grid(in, out, n, &vec, &grid)) return BD_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL(bd_u16_to_i16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
+    else     hipLaunchKernelGGL(bd_u16_to_i16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
     return bd_check_hip(hipGetLastError(), "launch bd_u16_to_i16_kernel");
 }
 
@@ -128,33 +213,21 @@ extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, voi
 {
     if ((!in || !out) && n) { bd_set_error("bd_f32_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n == 0) return BD_OK;
-    const uint64_t grid64 = (n + 255) / 256;
-    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bd_f32_to_i16_kernel, dim3((unsigned)grid64), dim3(256), 0,
-                       (hipStream_t)hip_stream, in, out, n);
+    bool vec; unsigned grid;
+    if (!bd_cvt_grid(in, out, n, &vec, &grid)) return BD_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL(bd_f32_to_i16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
+    else     hipLaunchKernelGGL(bd_f32_to_i16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
     return bd_check_hip(hipGetLastError(), "launch bd_f32_to_i16_kernel");
-}
-
-// Down-mix of interleaved stereo frames as the reference's test harness does it
-// (src/lib.rs:310-337: `((l as i32 + r as i32) as f32 / 2.0) as i16`, i.e. the sum halved
-// with truncation toward zero; the sum of two i16 is exact in f32).  One thread per frame,
-// a 4-byte load and a 2-byte store each.
-__global__ void bd_stereo_to_mono_kernel(const int16_t *in, int16_t *out, uint64_t n_frames)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_frames) return;
-    const int32_t sum = (int32_t)in[2 * i] + (int32_t)in[2 * i + 1];
-    out[i] = (int16_t)(sum / 2); // C division truncates toward zero, like the f32 -> i16 cast
 }
 
 extern "C" int bd_stereo_to_mono(const int16_t *interleaved, int16_t *mono, uint64_t n_frames, void *hip_stream)
 {
     if ((!interleaved || !mono) && n_frames) { bd_set_error("bd_stereo_to_mono: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n_frames == 0) return BD_OK;
-    const uint64_t grid64 = (n_frames + 255) / 256;
-    if (grid64 > 0x7fffffffull) return BD_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(bd_stereo_to_mono_kernel, dim3((unsigned)grid64), dim3(256), 0,
-                       (hipStream_t)hip_stream, interleaved, mono, n_frames);
+    bool vec; unsigned grid;
+    if (!bd_cvt_grid(interleaved, mono, n_frames, &vec, &grid)) return BD_ERR_UNSUPPORTED;
+    if (vec) hipLaunchKernelGGL(bd_stereo_to_mono_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, interleaved, mono, n_frames);
+    else     hipLaunchKernelGGL(bd_stereo_to_mono_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, interleaved, mono, n_frames);
     return bd_check_hip(hipGetLastError(), "launch bd_stereo_to_mono_kernel");
 }
 

@@ -384,6 +384,24 @@ def test_stereo_downmix_matches_reference(bd, oracle):
         np.testing.assert_array_equal(got[r], oracle.stereo_to_mono(st[r]))
 
 
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 1000, 4099])
+@pytest.mark.parametrize("shift", [0, 1, 3])
+def test_converters_lengths_and_alignments(bd, oracle, n, shift):
+    """Whole 16-byte units, tails of 1 .. 7 samples, and buffers that start off a 16-byte boundary."""
+    torch = _torch()
+    rng = np.random.default_rng(n * 7 + shift)
+    u = rng.integers(0, 65536, n + shift).astype(np.uint16)
+    got = bd.u16_data_to_i16(torch.from_numpy(u.view(np.int16)).cuda()[shift:]).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.u16_data_to_i16(u[shift:]))
+    f = rng.uniform(-1.3, 1.3, n + shift).astype(np.float32)
+    f[::5] = np.nan if n > 20 else f[::5]
+    got = bd.f32_data_to_i16(torch.from_numpy(f).cuda()[shift:]).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.f32_data_to_i16(f[shift:]))
+    st = rng.integers(-32768, 32768, 2 * (n + shift)).astype(np.int16)
+    got = bd.stereo_to_mono(torch.from_numpy(st).cuda()[2 * shift:]).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.stereo_to_mono(st[2 * shift:]))
+
+
 def test_generator_device_equals_host(bd):
     torch = _torch()
     for n_streams, n, first in ((5, 44100 * 3 + 5, 0), (3, 1000, 77), (2, 8, 5), (1, 7, 2)):
