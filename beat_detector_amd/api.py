@@ -177,6 +177,7 @@ def lib() -> C.CDLL:
         "bd_batch_callbacks": (u64, [u64, u32]),
         "bd_batch_max_beats": (u32, [u32, u32, pp, u64, u32]),
         "bd_analyze_batch": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_analyze_batch_noalloc": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, u32, vp]),
         "bd_analyze_batch_ragged": (i32, [i32, u32, pp, vp, u64, vp, u64, u64, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
         "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp]),
         "bd_analyze_batch_host": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, i32]),
@@ -219,7 +220,7 @@ EXPORTED_SYMBOLS = (
     "bd_default_params bd_strerror bd_last_error bd_device_count bd_kind_count bd_kind_name "
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
-    "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
+    "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_noalloc bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
@@ -463,6 +464,29 @@ def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len:
                                       _row_stride(out.flags, out.values), out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
                                       out.beat_idx.shape[1], _stream_ptr(stream)))
     return out
+
+
+NOALLOC_MAX_CALLBACKS = 96 << 20  # BD_NOALLOC_SCRATCH_BYTES of include/beat_detector_hip.h
+
+
+def analyze_batch_noalloc(kind: StrategyKind, sampling_rate: int, samples, callback_len: int, beat_count, beat_idx,
+                          beat_ms, n_samples: Optional[int] = None, params: Optional[Params] = None,
+                          stream=None) -> None:
+    """bd_analyze_batch_noalloc: beat lists only, into tensors the caller already owns (CUDA int32
+    [n_streams], [n_streams, max_beats] x 2); the per-callback decisions stay in the library's fixed
+    device array, so nothing is allocated by the call."""
+    _require_cuda(samples, torch.int16, "samples")
+    _require_cuda(beat_count, torch.int32, "beat_count")
+    _require_cuda(beat_idx, torch.int32, "beat_idx")
+    _require_cuda(beat_ms, torch.int32, "beat_ms")
+    n_streams, stride = samples.shape
+    n = stride if n_samples is None else n_samples
+    if beat_count.shape != (n_streams,) or beat_idx.shape != beat_ms.shape or beat_idx.shape[0] != n_streams:
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "beat outputs must be [n_streams] and [n_streams, max_beats]")
+    with torch.cuda.device(samples.device):
+        _check(lib().bd_analyze_batch_noalloc(kind.value, sampling_rate, _pp(params), samples.data_ptr(), n_streams, n,
+                                              stride, callback_len, beat_count.data_ptr(), beat_idx.data_ptr(),
+                                              beat_ms.data_ptr(), beat_idx.shape[1], _stream_ptr(stream)))
 
 
 def analyze_batch_ragged(kind: StrategyKind, sampling_rate: int, samples, lengths, callback_len: int,

@@ -185,6 +185,25 @@ int bd_refractory(uint32_t sampling_rate, const bd_params *params, uint32_t call
                   uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                   uint32_t max_beats, void *hip_stream);
 
+/* bd_analyze_batch without the `flags` / `values` arguments, for callers that
+ * cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.
+ * The per-callback decisions that bd_analyze_batch keeps in the caller's
+ * `flags` live in a fixed device array inside the library (one copy per GPU,
+ * BD_NOALLOC_SCRATCH_BYTES, held until the process ends); the call allocates
+ * and frees nothing and only enqueues on `hip_stream`.  Limit: n_streams *
+ * (n_samples / callback_len) <= BD_NOALLOC_SCRATCH_BYTES (one byte per
+ * callback), else BD_ERR_UNSUPPORTED.  The first call on a device looks up that
+ * device's copy of the array (make it before a graph capture starts).  All calls on one GPU share that array: calls that overlap
+ * in time on the same GPU race and must be serialised by the caller (calls on
+ * one HIP stream are).  Beat lists equal bd_analyze_batch's. */
+#define BD_NOALLOC_SCRATCH_BYTES (96ull << 20)
+int bd_analyze_batch_noalloc(int kind, uint32_t sampling_rate, const bd_params *params,
+                             const int16_t *samples, uint64_t n_streams, uint64_t n_samples,
+                             uint64_t stream_stride, uint32_t callback_len,
+                             uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
+                             uint32_t max_beats, void *hip_stream);
+
 /* ---- live path ----------------------------------------------------------- */
 /* Sample formats of an input device (cpal::SampleFormat, src/record.rs:90-133). */
 #define BD_FMT_I16 0
