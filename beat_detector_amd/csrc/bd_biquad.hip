@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, BD_BQ_WAVES) void bd_biquad_env_kernel(bd_bq_a
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t s = bd_block_index() * 4 + wave;
     if (s >= a.n_streams) return;
     uint32_t *tile = tile_all[wave];
     const int16_t *sp = a.samples + s * a.stride;
@@ -304,8 +304,9 @@ extern "C" int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params
     a.misaligned = (((uintptr_t)samples % 16) || (stream_stride % 8)) ? 1u : 0u;
     a.lanes_per_window = w / 64; a.min_amp = p.min_amplitude; a.ratio = p.ratio;
     const uint64_t grid64 = (n_streams + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(bd_biquad_env_kernel, dim3((unsigned)grid64), dim3(256), 0, (hipStream_t)hip_stream, a);
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_biquad_env_kernel, grid_dims, dim3(256), 0, (hipStream_t)hip_stream, a);
     bd_set_last_kernel("bd_biquad_env_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_biquad_env_kernel");
 }

@@ -57,6 +57,21 @@ int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8
                          uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
                          hipStream_t st, const uint64_t *lengths = nullptr);
 
+// One grid dimension holds fewer than 2^32 threads (blocks x threads per block); the runtime
+// cuts a larger launch short without an error.  Launches therefore fold their blocks into two
+// dimensions, rows of at most BD_GRID_ROW_BLOCKS blocks (of at most 256 threads), and kernels
+// number their blocks with bd_block_index(); blocks past the last task find nothing to do.
+#define BD_GRID_ROW_BLOCKS 0x400000ull
+static inline bool bd_grid_dims(uint64_t blocks, dim3 *grid)
+{
+    if (blocks == 0) blocks = 1;
+    if (blocks <= BD_GRID_ROW_BLOCKS) { *grid = dim3((unsigned)blocks, 1, 1); return true; }
+    const uint64_t rows = (blocks + BD_GRID_ROW_BLOCKS - 1) / BD_GRID_ROW_BLOCKS;
+    if (rows > 65535ull) return false;
+    *grid = dim3((unsigned)((blocks + rows - 1) / rows), (unsigned)rows, 1);
+    return true;
+}
+
 // Rust `as` casts on the host
 static inline uint32_t bd_f32_as_u32(float x)
 {
@@ -68,6 +83,11 @@ static inline uint32_t bd_f32_as_u32(float x)
 
 // ---- device helpers -------------------------------------------------------
 #if defined(__HIPCC__)
+
+__device__ __forceinline__ uint64_t bd_block_index()
+{
+    return (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
+}
 
 // 16-byte streaming load (data is read once: keep it out of the way in the caches)
 typedef unsigned int bd_u32x4 __attribute__((ext_vector_type(4)));

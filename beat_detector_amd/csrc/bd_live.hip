@@ -334,7 +334,7 @@ extern "C" int bd_detector_last(const bd_detector *d, float *value, int *candida
 
 __global__ void bd_live_convert_kernel(const void *in, int16_t *out, uint64_t n, int format)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (format == BD_FMT_U16) {
         const int32_t x = (int32_t)((const uint16_t *)in)[i] - (int32_t)(INT16_MAX / 2); // record.rs:154-155

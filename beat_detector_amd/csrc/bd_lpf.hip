@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     __shared__ uint4 tile_all[WPB][64 * BD_LPF_ROW_U4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint4 *tile = tile_all[wave];
-    const uint64_t task = (uint64_t)blockIdx.x * WPB + wave;
+    const uint64_t task = bd_block_index() * WPB + wave;
     if (task >= a.n_tasks) return; // wave-uniform
     const uint64_t s = task / a.groups_per_stream;
     const uint64_t j0 = (task - s * a.groups_per_stream) * 64;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
 
 __global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n_cb, uint64_t out_stride, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (i < n) {
         const uint64_t o = (i / n_cb) * out_stride + i % n_cb;
         if (values) values[o] = 0.f;
@@ -251,8 +251,9 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
         // filtered sample becomes 0 and no window can reach its threshold
         const uint64_t n = n_streams * n_cb;
         const uint64_t grid64 = (n + 255) / 256;
-        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(bd_fill_zero_kernel, dim3((unsigned)grid64), dim3(256), 0, st, values, flags, n_cb, out_stride, n);
+        dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(bd_fill_zero_kernel, grid_dims, dim3(256), 0, st, values, flags, n_cb, out_stride, n);
         bd_set_last_kernel("bd_fill_zero_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_fill_zero_kernel");
     }
@@ -277,15 +278,16 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
     const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
     const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;
-    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     if (!aligned)
-        hipLaunchKernelGGL((bd_lpf_window_kernel<false, 64, 4>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((bd_lpf_window_kernel<false, 64, 4>), grid_dims, dim3(256), 0, st, a);
     else if (variant == 1)
-        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 1>), dim3((unsigned)grid64), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 1>), grid_dims, dim3(64), 0, st, a);
     else if (variant == 2)
-        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 2>), dim3((unsigned)grid64), dim3(128), 0, st, a);
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 2>), grid_dims, dim3(128), 0, st, a);
     else
-        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 64, 4>), dim3((unsigned)grid64), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((bd_lpf_window_kernel<true, 64, 4>), grid_dims, dim3(256), 0, st, a);
     bd_set_last_kernel("bd_lpf_window_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_lpf_window_kernel");
 }

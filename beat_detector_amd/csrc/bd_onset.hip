@@ -250,7 +250,7 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
     }
     __syncthreads();
     v2f *tile = tile_all[wave];
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint64_t f0 = (task - s * a.runs_per_stream) * a.run_frames;
@@ -480,7 +480,7 @@ struct bd_pick_args {
 __global__ __launch_bounds__(256) void bd_peak_pick_kernel(bd_pick_args a)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t s = bd_block_index() * 4 + (threadIdx.x >> 6);
     if (s >= a.n_streams) return;
     const float *fl = a.flux + s * a.out_stride;
     const int64_t n = (int64_t)a.n_frames;
@@ -591,15 +591,16 @@ extern "C" int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, c
     for (uint32_t k = 0; k <= p->fft_len / 2; k++) { if ((float)k * res <= p->band_max_hz) kmax = k; else break; }
     a.kmax = kmax; a.window = p->window ? 1u : 0u;
     const uint64_t grid64 = (a.n_tasks + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)hip_stream;
     const bool half = p->hop == p->fft_len / 2;
     if (p->fft_len == 2048) {
-        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<16, 2>), dim3((unsigned)grid64), dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((bd_stft_flux_kernel<16, 1>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<16, 2>), grid_dims, dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((bd_stft_flux_kernel<16, 1>), grid_dims, dim3(256), 0, s, a);
     } else {
-        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<8, 2>), dim3((unsigned)grid64), dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((bd_stft_flux_kernel<8, 1>), dim3((unsigned)grid64), dim3(256), 0, s, a);
+        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<8, 2>), grid_dims, dim3(256), 0, s, a);
+        else      hipLaunchKernelGGL((bd_stft_flux_kernel<8, 1>), grid_dims, dim3(256), 0, s, a);
     }
     bd_set_last_kernel("bd_stft_flux_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_stft_flux_kernel");
@@ -625,8 +626,9 @@ extern "C" int bd_onset_pick(uint32_t sampling_rate, const bd_onset_params *p, c
     a.delta = p->delta; a.lambda = p->lambda; a.use_median = p->use_median ? 1u : 0u;
     if (a.use_median && p->mean_frames > 32) { bd_set_error("bd_onset_pick: the median threshold supports mean_frames <= 32"); return BD_ERR_UNSUPPORTED; }
     const uint64_t grid64 = (n_streams + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(bd_peak_pick_kernel, dim3((unsigned)grid64), dim3(256), 0, (hipStream_t)hip_stream, a);
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_peak_pick_kernel, grid_dims, dim3(256), 0, (hipStream_t)hip_stream, a);
     return bd_check_hip(hipGetLastError(), "launch bd_peak_pick_kernel");
 }
 

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void bd_refractory_kernel(
     uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t s = bd_block_index() * 4 + (threadIdx.x >> 6);
     if (s >= n_streams) return; // wave-uniform
     const uint8_t *f = flags + s * flags_stride;
     // a stream shorter than the batch stops at its own last complete callback
@@ -66,8 +66,9 @@ int bd_launch_refractory(const bd_plan &plan, uint32_t callback_len, const uint8
     uint32_t step_ms, half_ms;
     bd_clock_step(plan, callback_len, &step_ms, &half_ms);
     const uint64_t grid64 = (n_streams + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(bd_refractory_kernel, dim3((unsigned)grid64), dim3(256), 0, st,
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("too many streams for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_refractory_kernel, grid_dims, dim3(256), 0, st,
                        flags, flags_stride, n_streams, n_cb, lengths, callback_len, step_ms, half_ms, plan.gap_ms,
                        beat_count, beat_idx, beat_ms, max_beats);
     return bd_check_hip(hipGetLastError(), "launch bd_refractory_kernel");

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const int g = lane >> 4, l = lane & 15;
     // everything that selects the task is the same in all lanes: keep it scalar
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint32_t r = (uint32_t)(task - s * a.runs_per_stream);
@@ -273,7 +273,7 @@ struct bd_spec_generic_args {
 __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generic_args a)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t t = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t t = bd_block_index() * 4 + (threadIdx.x >> 6);
     if (t >= a.n_total) return;
     const uint64_t s = t / a.n_cb, j = t - s * a.n_cb;
     const int16_t *sp = a.samples + s * a.stride;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint64_t j0 = a.j_min + (task - s * a.runs_per_stream) * 64;
@@ -541,13 +541,13 @@ __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
 }
 
 template <int NK, bool NYQ>
-static void bd_win_launch2(bool whole, const bd_win_args &a, unsigned grid, hipStream_t st)
+static void bd_win_launch2(bool whole, const bd_win_args &a, dim3 grid, hipStream_t st)
 {
     if (whole) hipLaunchKernelGGL((bd_spectrum_window_kernel<NK, NYQ, true>), dim3(grid), dim3(256), 0, st, a);
     else       hipLaunchKernelGGL((bd_spectrum_window_kernel<NK, NYQ, false>), dim3(grid), dim3(256), 0, st, a);
 }
 template <int NK>
-static void bd_win_launch(bool nyq, bool whole, const bd_win_args &a, unsigned grid, hipStream_t st)
+static void bd_win_launch(bool nyq, bool whole, const bd_win_args &a, dim3 grid, hipStream_t st)
 {
     if (nyq) bd_win_launch2<NK, true>(whole, a, grid, st);
     else     bd_win_launch2<NK, false>(whole, a, grid, st);
@@ -555,7 +555,7 @@ static void bd_win_launch(bool nyq, bool whole, const bd_win_args &a, unsigned g
 
 // ---- launcher ---------------------------------------------------------------
 template <int MODE, int NK>
-static void launch_fast(bool nyq, const bd_spec_args &a, unsigned grid, unsigned lds_pad, hipStream_t st)
+static void launch_fast(bool nyq, const bd_spec_args &a, dim3 grid, unsigned lds_pad, hipStream_t st)
 {
     if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true>), dim3(grid), dim3(256), lds_pad, st, a);
     else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false>), dim3(grid), dim3(256), lds_pad, st, a);
@@ -591,8 +591,9 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
         a.divisor = plan.divisor; a.threshold = plan.threshold;
         const uint64_t grid64 = (a.n_tasks + 3) / 4;
-        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-        const unsigned grid = (unsigned)grid64;
+        dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        const dim3 grid = grid_dims;
         // unused dynamic LDS caps the workgroups resident per CU (tuning knob, read at every launch)
         const char *pad_env = getenv("BD_SPEC_LDS_PAD");
         unsigned lds_pad = pad_env ? (unsigned)atoi(pad_env) : 0;
@@ -639,8 +640,9 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
         a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;
         const uint64_t grid64 = (a.n_total + 3) / 4;
-        if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(bd_spectrum_generic_kernel, dim3((unsigned)grid64), dim3(256), 0, st, a);
+        dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(bd_spectrum_generic_kernel, grid_dims, dim3(256), 0, st, a);
         bd_set_last_kernel("bd_spectrum_generic_kernel");
         int rc = bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
         if (rc != BD_OK || n_generic == n_cb) return rc;
@@ -655,18 +657,19 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     a.callback_len = callback_len; a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
     a.divisor = plan.divisor; a.threshold = plan.threshold;
     const uint64_t grid64 = (a.n_tasks + 3) / 4;
-    if (grid64 > 0x7fffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
     const bool whole = callback_len % 16 == 0 || callback_len >= BD_RING_LEN;
     a.nk_keep = (uint32_t)plan.last_bin;
-    if (plan.last_bin == 0) bd_win_launch<0>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin == 1) bd_win_launch<1>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin == 2) bd_win_launch<2>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin == 3) bd_win_launch<3>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin == 4) bd_win_launch<4>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin == 5) bd_win_launch<5>(nyq, whole, a, (unsigned)grid64, st);
-    else if (plan.last_bin <= 8) bd_win_launch<8>(nyq, whole, a, (unsigned)grid64, st);
-    else bd_win_launch<11>(nyq, whole, a, (unsigned)grid64, st);
+    if (plan.last_bin == 0) bd_win_launch<0>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin == 1) bd_win_launch<1>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin == 2) bd_win_launch<2>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin == 3) bd_win_launch<3>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin == 4) bd_win_launch<4>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin == 5) bd_win_launch<5>(nyq, whole, a, grid_dims, st);
+    else if (plan.last_bin <= 8) bd_win_launch<8>(nyq, whole, a, grid_dims, st);
+    else bd_win_launch<11>(nyq, whole, a, grid_dims, st);
     bd_set_last_kernel("bd_spectrum_window_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_spectrum_window_kernel");
 }

@@ -99,7 +99,7 @@ __device__ __forceinline__ void bd_spectrum_granule_body(const bd_gr_args &a)
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint64_t r = task - s * a.runs_per_stream;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 3) void bd_spectrum_g63_kernel(bd_gr_args a)
 
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t task = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const uint64_t r = task - s * a.runs_per_stream;
@@ -489,14 +489,14 @@ __global__ __launch_bounds__(256, 3) void bd_spectrum_g63_kernel(bd_gr_args a)
 }
 
 template <int NK>
-static void bd_g63_launch(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+static void bd_g63_launch(bool nyq, const bd_gr_args &a, dim3 grid, hipStream_t st)
 {
     if (nyq) hipLaunchKernelGGL((bd_spectrum_g63_kernel<NK, true>), dim3(grid), dim3(256), 0, st, a);
     else     hipLaunchKernelGGL((bd_spectrum_g63_kernel<NK, false>), dim3(grid), dim3(256), 0, st, a);
 }
 
 template <int NK, int G>
-static void bd_gr_launch2(bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+static void bd_gr_launch2(bool nyq, const bd_gr_args &a, dim3 grid, hipStream_t st)
 {
     if (NK >= 8) {
         if (nyq) hipLaunchKernelGGL((bd_spectrum_granule_kernel_w2<NK, true, G>), dim3(grid), dim3(256), 0, st, a);
@@ -507,7 +507,7 @@ static void bd_gr_launch2(bool nyq, const bd_gr_args &a, unsigned grid, hipStrea
     else     hipLaunchKernelGGL((bd_spectrum_granule_kernel<NK, false, G>), dim3(grid), dim3(256), 0, st, a);
 }
 template <int NK>
-static void bd_gr_launch(uint32_t gran, bool nyq, const bd_gr_args &a, unsigned grid, hipStream_t st)
+static void bd_gr_launch(uint32_t gran, bool nyq, const bd_gr_args &a, dim3 grid, hipStream_t st)
 {
     if (gran == 64) bd_gr_launch2<NK, 64>(nyq, a, grid, st);
     else if (gran == 32) bd_gr_launch2<NK, 32>(nyq, a, grid, st);
@@ -561,9 +561,10 @@ int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint
     a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
     a.divisor = plan.divisor; a.threshold = plan.threshold;
     const uint64_t grid64 = (a.n_tasks + 3) / 4;
-    if (grid64 > 0x7fffffffull || n_steps > 0xffffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims) || n_steps > 0xffffffffull) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
-    const unsigned grid = (unsigned)grid64;
+    const dim3 grid = grid_dims;
     a.nk_keep = (uint32_t)plan.last_bin;
     if (plan.last_bin > bd_spectrum_granule_max_bins(gran)) { bd_set_error("too many bins for this granule size"); return BD_ERR_UNSUPPORTED; }
     if (gran == 63) {

@@ -22,14 +22,46 @@ __global__ __launch_bounds__(256) void bd_synth_kernel(int16_t *samples, uint64_
                                                        uint32_t sampling_rate, uint64_t groups_per_stream)
 {
     // one thread per group of 8 consecutive samples
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = bd_block_index() * blockDim.x + threadIdx.x;
     if (t >= n_streams * groups_per_stream) return;
     const uint64_t s = t / groups_per_stream;
     const uint64_t n0 = (t - s * groups_per_stream) * 8;
     const bd_synth_stream p = bd_synth_stream_params(seed, first_stream + s, sampling_rate);
+    // bd_synth_sample() for n0 .. n0 + 7 with the position inside the click pattern carried from
+    // sample to sample (one division per thread instead of one per sample); same bits
     int16_t v[8];
+    uint64_t ci = 0;
+    uint32_t phase = 0, level = 0;
+    bool level_known = false;
+    // samples before `skip` precede the first click (8: the whole group does)
+    const int skip = n0 >= p.offset ? 0 : (p.offset - n0 < 8 ? (int)(p.offset - n0) : 8);
+    if (skip < 8) {
+        const uint64_t rel = n0 + (uint64_t)skip - p.offset;
+        ci = rel >> 32 ? rel / p.period : (uint64_t)((uint32_t)rel / p.period);
+        phase = (uint32_t)(rel - ci * p.period);
+    }
+    // the noise hash takes n in 32-bit halves; the high half is constant inside a group of 8
+    uint32_t hk = p.key + (uint32_t)n0 * 0x9E3779B1u + (uint32_t)(n0 >> 32);
 #pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = bd_synth_sample(p, bd_click_dev, n0 + i);
+    for (int i = 0; i < 8; i++) {
+        const uint32_t h = bd_mix32(hk);
+        hk += 0x9E3779B1u;
+        int32_t x = (int32_t)(((h >> 16) * 1001u) >> 16) - 500;
+        if (i >= skip) {
+            if (phase < BD_CLICK_LEN) {
+                if (!level_known) {
+                    const uint32_t jitter = 768u + bd_mix32(p.click_key ^ (uint32_t)ci) % 257u;
+                    level = (uint32_t)(((int64_t)p.level_q15 * jitter) >> 10);
+                    level_known = true;
+                }
+                x += (int32_t)(((int64_t)bd_click_dev[phase] * (int64_t)level) >> 15);
+            }
+            if (++phase == p.period) { phase = 0; ci++; level_known = false; }
+        }
+        x = x > 32767 ? 32767 : x;
+        x = x < -32768 ? -32768 : x;
+        v[i] = (int16_t)x;
+    }
     int16_t *dst = samples + s * stride + n0;
     if (n0 + 8 <= n_samples && ((uintptr_t)dst % 16 == 0)) {
         uint4 pk;
@@ -70,8 +102,9 @@ extern "C" int bd_synth_fill(int16_t *samples, uint64_t n_streams, uint64_t n_sa
     }
     const uint64_t groups = (n_samples + 7) / 8;
     const uint64_t grid64 = (n_streams * groups + 255) / 256;
-    if (grid64 > 0x7fffffffull) { bd_set_error("bd_synth_fill: batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-    hipLaunchKernelGGL(bd_synth_kernel, dim3((unsigned)grid64), dim3(256), 0, st,
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("bd_synth_fill: batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(bd_synth_kernel, grid_dims, dim3(256), 0, st,
                        samples, n_streams, n_samples, stream_stride, first_stream, seed,
                        sampling_rate, groups);
     return bd_check_hip(hipGetLastError(), "launch bd_synth_kernel");
@@ -131,7 +164,7 @@ __device__ __forceinline__ void bd_store_unit(int16_t *out, uint64_t unit, const
 template <bool VEC>
 __global__ __launch_bounds__(256) void bd_u16_to_i16_kernel(const uint16_t *in, int16_t *out, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (!VEC) { if (i < n) out[i] = bd_cvt_u16(in[i]); return; }
     const uint64_t units = n / 8;
     if (i < units) {
@@ -149,7 +182,7 @@ __global__ __launch_bounds__(256) void bd_u16_to_i16_kernel(const uint16_t *in, 
 template <bool VEC>
 __global__ __launch_bounds__(256) void bd_f32_to_i16_kernel(const float *in, int16_t *out, uint64_t n)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (!VEC) { if (i < n) out[i] = bd_cvt_f32(in[i]); return; }
     const uint64_t units = n / 8;
     if (i < units) {
@@ -169,7 +202,7 @@ __global__ __launch_bounds__(256) void bd_f32_to_i16_kernel(const float *in, int
 template <bool VEC>
 __global__ __launch_bounds__(256) void bd_stereo_to_mono_kernel(const int16_t *in, int16_t *out, uint64_t n_frames)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (!VEC) { if (i < n_frames) out[i] = bd_cvt_stereo(in[2 * i], in[2 * i + 1]); return; }
     const uint64_t units = n_frames / 8;
     if (i < units) {
@@ -188,13 +221,14 @@ __global__ __launch_bounds__(256) void bd_stereo_to_mono_kernel(const int16_t *i
 }
 
 // threads of a launch: one per 16-byte unit plus one for the tail, or one per sample
-static bool bd_cvt_grid(const void *in, const void *out, uint64_t n, bool *vec, unsigned *grid)
+static bool bd_cvt_grid(const void *in, const void *out, uint64_t n, bool *vec, dim3 *grid)
 {
     *vec = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0);
     const uint64_t threads = *vec ? n / 8 + 1 : n;
     const uint64_t grid64 = (threads + 255) / 256;
-    if (grid64 > 0x7fffffffull) { bd_set_error("buffer too large for one launch"); return false; }
-    *grid = (unsigned)grid64;
+    dim3 grid_dims;
+    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("buffer too large for one launch"); return false; }
+    *grid = grid_dims;
     return true;
 }
 
@@ -202,7 +236,7 @@ extern "C" int bd_u16_data_to_i16(const uint16_t *in, int16_t *out, uint64_t n, 
 {
     if ((!in || !out) && n) { bd_set_error("bd_u16_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n == 0) return BD_OK;
-    bool vec; unsigned grid;
+    bool vec; dim3 grid;
     if (!bd_cvt_grid(in, out, n, &vec, &grid)) return BD_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL(bd_u16_to_i16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
     else     hipLaunchKernelGGL(bd_u16_to_i16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
@@ -213,7 +247,7 @@ extern "C" int bd_f32_data_to_i16(const float *in, int16_t *out, uint64_t n, voi
 {
     if ((!in || !out) && n) { bd_set_error("bd_f32_data_to_i16: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n == 0) return BD_OK;
-    bool vec; unsigned grid;
+    bool vec; dim3 grid;
     if (!bd_cvt_grid(in, out, n, &vec, &grid)) return BD_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL(bd_f32_to_i16_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
     else     hipLaunchKernelGGL(bd_f32_to_i16_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, in, out, n);
@@ -224,7 +258,7 @@ extern "C" int bd_stereo_to_mono(const int16_t *interleaved, int16_t *mono, uint
 {
     if ((!interleaved || !mono) && n_frames) { bd_set_error("bd_stereo_to_mono: null pointer"); return BD_ERR_INVALID_ARG; }
     if (n_frames == 0) return BD_OK;
-    bool vec; unsigned grid;
+    bool vec; dim3 grid;
     if (!bd_cvt_grid(interleaved, mono, n_frames, &vec, &grid)) return BD_ERR_UNSUPPORTED;
     if (vec) hipLaunchKernelGGL(bd_stereo_to_mono_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, interleaved, mono, n_frames);
     else     hipLaunchKernelGGL(bd_stereo_to_mono_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)hip_stream, interleaved, mono, n_frames);
@@ -241,7 +275,7 @@ extern "C" int bd_stereo_to_mono(const int16_t *interleaved, int16_t *mono, uint
 template <int DEPTH>
 __global__ __launch_bounds__(256) void bd_probe_read_kernel(const uint4 *src, uint64_t n_units, uint32_t *sink, int contiguous)
 {
-    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint64_t wave = (bd_block_index() * 256 + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * 256) >> 6;
     const int lane = threadIdx.x & 63;
     constexpr uint64_t STEP = 64 * DEPTH; // units per wavefront step

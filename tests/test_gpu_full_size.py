@@ -18,6 +18,12 @@ def _batch(bd, n_streams, seconds, seed=0x5EED):
     n = SR * seconds
     buf = torch.empty((n_streams, (n + 63) & ~63), dtype=torch.int16, device="cuda")
     bd.synth_fill(buf, n_samples=n, seed=seed, sampling_rate=SR)
+    # the generator's launch covers every stream of the batch (more than 2^32 threads at this size)
+    for s in (0, n_streams // 2, n_streams - 1):
+        want = bd.synth_fill_host(1, 50000, first_stream=s, seed=seed, sampling_rate=SR)[0]
+        assert np.array_equal(buf[s, :50000].cpu().numpy(), want), s
+        assert np.array_equal(buf[s, n - 50000:n].cpu().numpy(),
+                              bd.synth_fill_host(1, n, first_stream=s, seed=seed, sampling_rate=SR)[0][n - 50000:]), s
     return buf, n
 
 
