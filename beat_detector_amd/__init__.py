@@ -43,3 +43,4 @@ from .api import (  # noqa: F401
 )
 from .onset import OnsetResult, onset_batch, onset_frames, onset_pick, onset_stft  # noqa: F401,E402
 from .biquad import biquad_beats, biquad_design, biquad_envelope  # noqa: F401,E402
+from .executor import ChunkedExecutor, SynthSource  # noqa: F401,E402

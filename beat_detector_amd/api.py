@@ -203,6 +203,13 @@ def lib() -> C.CDLL:
         "bd_onset_batch": (i32, [u32, op, vp, u64, u64, u64, vp, vp, u64, vp, vp, vp, u32, vp]),
         "bd_probe_read": (i32, [vp, u64, vp, u32, vp]),
         "bd_probe_read_ex": (i32, [vp, u64, vp, u32, u32, u32, vp]),
+        "bd_chunk_source_synth": (i32, [vp, vp, u64, u64, u64, u64, vp]),
+        "bd_chunked_create": (i32, [u64, u64, i32, C.POINTER(vp)]),
+        "bd_chunked_device_bytes": (u64, [vp]),
+        "bd_chunked_analyze": (i32, [vp, i32, u32, pp, u32, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_chunked_onset": (i32, [vp, u32, op, vp, vp, u64, vp, vp, vp, u32, vp]),
+        "bd_chunked_last_timing": (i32, [vp, vp, vp, u32]),
+        "bd_chunked_destroy": (None, [vp]),
         "bd_biquad_default_params": (None, [C.POINTER(BiquadParams)]),
         "bd_biquad_design_lowpass": (i32, [u32, u32, f32, C.POINTER(BiquadDesign)]),
         "bd_biquad_envelope": (i32, [u32, C.POINTER(BiquadParams), C.POINTER(BiquadDesign), vp, u64, u64, u64, vp, vp,
@@ -224,7 +231,8 @@ EXPORTED_SYMBOLS = (
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
-    "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope bd_probe_read bd_probe_read_ex"
+    "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope bd_probe_read bd_probe_read_ex "
+    "bd_chunk_source_synth bd_chunked_create bd_chunked_device_bytes bd_chunked_analyze bd_chunked_onset bd_chunked_last_timing bd_chunked_destroy"
 ).split()
 
 

@@ -11,14 +11,23 @@ GPUs every rank analyses its own 16,384 streams (weak scaling, no collective on
 the data path); the reported value is the audio-seconds all ranks analysed per
 wall-second, timed between barriers, maximum over ranks.
 
+With --gpus N > 1 and no launcher environment (RANK / WORLD_SIZE unset) the
+script starts its own N rank processes, one per GPU, before it touches the GPU;
+under `python -m torch.distributed.run` it is a rank as before.
+
 Rank 0 prints one JSON line.  `roofline` prices the dominant kernel against HBM
 bandwidth using HIP events recorded inside the timed region; `cpu_baseline` is
 the CPU restatement of the reference (oracle/) timed on this host's cores on a
-bounded sample of the same streams (N = 1 only).
+bounded sample of the same streams (N = 1 only); `also` holds short
+measurements of the other workloads (LPF, the extension analyses, one GPU's
+share of the 131,072-track job through the chunked executor, live latency),
+taken after and outside the headline's timed region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak (spec)
+SR = 44100
+SEED = 0x5EED
 
 WORKLOADS = {
     # name: (kind, callback_len, streams, seconds, description)
@@ -40,6 +51,10 @@ WORKLOADS = {
     # callback lengths off the 64-sample grid (10 ms of audio at 44.1 kHz): other kernels behind the same entry
     "spectrum_441": ("Spectrum", 441, 16384, 60,
                      "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, 441-sample callbacks "
+                     "against the 1024-sample ring"),
+    # the callback size the reference's author reports on Linux ("mostly 500-540", spectrum.rs:40-42)
+    "spectrum_529": ("Spectrum", 529, 16384, 60,
+                     "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, 529-sample callbacks "
                      "against the 1024-sample ring"),
     "lpf_441": ("LPF", 441, 4096, 60,
                 "LPF strategy batched: 4,096 synthetic click-track streams x 60 s @ 44.1 kHz, 441-sample windows"),
@@ -56,72 +71,150 @@ WORKLOADS = {
     "onset_2048_hop512": ("Onset", 512, 4096, 300,
                           "Extension mode: 4,096 synthetic 5-min tracks per GPU, 2048-pt Hann STFT hop 512 (75 % "
                           "overlap), spectral flux + band energy + adaptive peak picking"),
+    # one GPU's share of the 131,072-track job: more samples than HBM holds, through the chunked executor
+    "onset_2048_chunked": ("OnsetChunked", 1024, 16384, 300,
+                           "Extension mode, stream-sharded job of 131,072 synthetic 5-min tracks over 8 GPUs: 16,384 "
+                           "tracks per GPU (433 GB of samples) in chunks of 4,096 tracks, chunk c+1 synthesised on a "
+                           "side stream while chunk c is analysed; 2048-pt Hann STFT hop 1024, spectral flux + adaptive "
+                           "peak picking"),
 }
 # FFT length of the onset workloads (callback_len is their hop)
-ONSET_FFT = {"onset_2048": 2048, "onset_1024": 1024, "onset_2048_hop512": 2048}
+ONSET_FFT = {"onset_2048": 2048, "onset_1024": 1024, "onset_2048_hop512": 2048, "onset_2048_chunked": 2048}
+METRIC = {"Spectrum": "1024-pt STFT", "LPF": "lowpass windows", "Biquad": "carried-state biquad"}
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="spectrum_hop512", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (testing only)")
-    ap.add_argument("--seconds", type=int, default=0, help="override stream length in seconds (testing only)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams in the CPU baseline sample")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for the barrier / timing reduction (gloo: rehearsals)")
-    ap.add_argument("--share-device", action="store_true",
-                    help="rehearsal only: every rank uses GPU 0 (a box with one GPU)")
-    args = ap.parse_args()
+# --------------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher environment
+# --------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """Starts the N ranks as child processes (this process never touches the GPU) and waits."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:  # a rank failed: the others would wait at a barrier for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
+
+def rehearse_launch(args) -> None:
     import torch
-    import beat_detector_amd as bd
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    from beat_detector_amd import sharding
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    t = torch.tensor([1, rank, int(os.environ.get("LOCAL_RANK", "0"))], dtype=torch.int64)
     if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        streams = WORKLOADS[args.workload][2]
+        print(json.dumps({"rehearsal": "launch", "ranks": int(t[0]), "rank_sum": int(t[1]), "local_rank_sum": int(t[2]),
+                          "shards": [list(sharding.shard_range(world * streams, r, world)) for r in range(world)]}),
+              flush=True)
 
-    kind_name, L, streams, seconds, desc = WORKLOADS[args.workload]
-    if args.streams:
-        streams = args.streams
-    if args.seconds:
-        seconds = args.seconds
+
+class Ctx:
+    """Process-group plumbing shared by the measurements."""
+
+    def __init__(self, args):
+        import torch
+        import beat_detector_amd as bd
+        self.torch, self.bd, self.args = torch, bd, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != max(args.gpus, 1):
+            raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {self.world}")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+        if args.share_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        self.red_dev = self.dev if args.backend == "nccl" else torch.device("cpu")
+        self.lib = bd.lib()
+        self.st = torch.cuda.current_stream().cuda_stream
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, *xs):
+        if self.dist is None:
+            return xs
+        t = self.torch.tensor(list(xs), dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return tuple(float(v) for v in t)
+
+    def sum_over_ranks(self, x: int) -> int:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.int64, device=self.red_dev)
+        self.dist.all_reduce(t)
+        return int(t[0])
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.lib.bd_last_error().decode())
+
+    def first_stream(self, streams):
+        from beat_detector_amd import sharding
+        return sharding.shard_range(self.world * streams, self.rank, self.world)[0]
+
+
+# --------------------------------------------------------------------------------------------
+# a workload whose samples are resident in HBM
+# --------------------------------------------------------------------------------------------
+def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
+    """Measures one workload; returns (result dict, state kept for the CPU baseline)."""
+    import ctypes
+    torch, bd, L_ = ctx.torch, ctx.bd, ctx.lib
+    kind_name, L, d_streams, d_seconds, desc = WORKLOADS[workload]
+    streams = streams or d_streams
+    seconds = seconds or d_seconds
     onset = kind_name == "Onset"
     biquad = kind_name == "Biquad"
     kind = None if onset else bd.StrategyKind["LPF" if biquad else kind_name]
-    sr = 44100
+    sr, dev, st = SR, ctx.dev, ctx.st
     n = sr * seconds
     stride = (n + 63) & ~63  # rows start on 128-byte boundaries
-    seed = 0x5EED
     # weak scaling: `streams` per GPU, rank r owns the r-th contiguous shard of world * streams
-    from beat_detector_amd import sharding
-    first_stream = sharding.shard_range(world * streams, rank, world)[0]
+    first_stream = ctx.first_stream(streams)
 
     samples = torch.empty((streams, stride), dtype=torch.int16, device=dev)
-    bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=seed, sampling_rate=sr)
-    nfft = ONSET_FFT.get(args.workload, 0)
+    bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=SEED, sampling_rate=sr)
+    nfft = ONSET_FFT.get(workload, 0)
     if onset:
         oparams = bd.OnsetParams.default(fft_len=nfft, hop=L)
         n_cb = bd.onset_frames(n, nfft, L)               # frames per track
@@ -138,108 +231,74 @@ def main() -> None:
     ms = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    L_ = bd.lib()
-    st = torch.cuda.current_stream().cuda_stream
-
-    import ctypes
-
-    def stage1_onset():
-        # `values` holds the flux rows, `flags` the band-energy rows
-        rc = L_.bd_onset_stft(sr, ctypes.byref(oparams), samples.data_ptr(), streams, n, stride, values.data_ptr(),
-                              flags.data_ptr(), out_stride, st)
-        if rc != 0:
-            raise RuntimeError(L_.bd_last_error().decode())
-
-    def stage2_onset():
-        rc = L_.bd_onset_pick(sr, ctypes.byref(oparams), values.data_ptr(), streams, n_cb, out_stride, None,
-                              count.data_ptr(), idx.data_ptr(), ms.data_ptr(), max_beats, st)
-        if rc != 0:
-            raise RuntimeError(L_.bd_last_error().decode())
-
-    def stage1():
-        rc = L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
-                                    values.data_ptr(), flags.data_ptr(), out_stride, st)
-        if rc != 0:
-            raise RuntimeError(L_.bd_last_error().decode())
-
-    def stage2():
-        rc = L_.bd_refractory(sr, None, L, flags.data_ptr(), out_stride, streams, n_cb, count.data_ptr(), idx.data_ptr(),
-                              ms.data_ptr(), max_beats, st)
-        if rc != 0:
-            raise RuntimeError(L_.bd_last_error().decode())
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    bq_params = bd.BiquadParams.default(window_len=L) if biquad else None
-    bq_design = bd.biquad_design(sr, bq_params.cutoff_hz, bq_params.q_factor) if biquad else None
-
-    def stage1_biquad():
-        rc = L_.bd_biquad_envelope(sr, ctypes.byref(bq_params), ctypes.byref(bq_design), samples.data_ptr(), streams, n,
-                                   stride, values.data_ptr(), flags.data_ptr(), out_stride, st)
-        if rc != 0:
-            raise RuntimeError(L_.bd_last_error().decode())
-
     if onset:
-        stage1, stage2 = stage1_onset, stage2_onset
-    if biquad:
-        stage1 = stage1_biquad
+        def stage1():  # `values` holds the flux rows, `flags` the band-energy rows
+            ctx.check(L_.bd_onset_stft(sr, ctypes.byref(oparams), samples.data_ptr(), streams, n, stride,
+                                       values.data_ptr(), flags.data_ptr(), out_stride, st))
+
+        def stage2():
+            ctx.check(L_.bd_onset_pick(sr, ctypes.byref(oparams), values.data_ptr(), streams, n_cb, out_stride, None,
+                                       count.data_ptr(), idx.data_ptr(), ms.data_ptr(), max_beats, st))
+    else:
+        if biquad:
+            bq_params = bd.BiquadParams.default(window_len=L)
+            bq_design = bd.biquad_design(sr, bq_params.cutoff_hz, bq_params.q_factor)
+
+            def stage1():
+                ctx.check(L_.bd_biquad_envelope(sr, ctypes.byref(bq_params), ctypes.byref(bq_design), samples.data_ptr(),
+                                                streams, n, stride, values.data_ptr(), flags.data_ptr(), out_stride, st))
+        else:
+            def stage1():
+                ctx.check(L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
+                                                 values.data_ptr(), flags.data_ptr(), out_stride, st))
+
+        def stage2():
+            ctx.check(L_.bd_refractory(sr, None, L, flags.data_ptr(), out_stride, streams, n_cb, count.data_ptr(),
+                                       idx.data_ptr(), ms.data_ptr(), max_beats, st))
+
     stage1()
     launched = bd.last_kernel_name()      # the kernel the entry point routed this workload to
     stage2()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         stage1()
         stage2()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    barrier()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    ctx.barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         ev[k][0].record()
         stage1()                      # dominant kernel
         ev[k][1].record()
-        stage2()                      # refractory pass
+        stage2()                      # refractory pass / peak picking
         ev[k][2].record()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
     if os.environ.get("BENCH_VERBOSE"):
         print("per-step kernel ms:", [round(e[0].elapsed_time(e[1]), 3) for e in ev], file=sys.stderr)
-    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+    k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
     kernel_name = launched or {"Spectrum": "bd_spectrum_band_kernel", "LPF": "bd_lpf_window_kernel",
                                "Onset": "bd_stft_flux_kernel", "Biquad": "bd_biquad_env_kernel"}[kind_name]
-    total_beats = int(count.sum().item())
+    total_beats = ctx.sum_over_ranks(int(count.sum().item()))
+    elapsed, k1_ms = ctx.max_over_ranks(elapsed, k1_ms)
 
-    if dist is not None:
-        t = torch.tensor([elapsed, k1_ms], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, k1_ms = float(t[0]), float(t[1])
-        tb = torch.tensor([total_beats], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(tb)
-        total_beats = int(tb[0])
-
-    audio_sec_per_step = world * streams * (n / sr)
-    value = audio_sec_per_step * args.steps / elapsed
+    world = ctx.world
+    value = world * streams * (n / sr) * steps / elapsed
     # algorithmic bytes of one launch of the dominant kernel: every sample that
     # belongs to a callback read once (2 B) + 5 B written per callback
     alg_bytes = streams * (n_cb * L * 2 + n_cb * 5)
     if onset:  # every sample of a complete frame once + flux and band energy (8 B) per frame
         alg_bytes = streams * (((n_cb - 1) * L + nfft) * 2 + n_cb * 8) if n_cb else 0
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
-
+    traffic, traffic_source = _pmc_traffic(workload, streams, seconds)
     result = {
-        "metric": "audio-sec analysed/sec (node), " + {"Spectrum": "1024-pt STFT", "Onset": "%d-pt STFT" % nfft,
-                                                       "LPF": "lowpass windows",
-                                                       "Biquad": "carried-state biquad"}[kind_name],
+        "metric": "audio-sec analysed/sec (node), " + ("%d-pt STFT" % nfft if onset else METRIC[kind_name]),
         "value": value,
         "unit": "audio-sec/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -253,110 +312,264 @@ def main() -> None:
             "sampling_rate": sr,
             "callback_len": L,
             "callbacks_per_stream": n_cb,
-            "seed": seed,
+            "seed": SEED,
             "parallelism": f"stream-sharded x{world}, no collectives",
             "beats_found": total_beats,
         },
         "roofline": {
             "bound": "hbm",
-            "note": ("this kernel is limited by f32 VALU issue (a 2048-point FFT per 1024 new samples), not by HBM; "
-                     "the HBM fraction is reported for comparison with the other workloads") if onset else None,
             "kernel": kernel_name,
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic(args.workload, streams, seconds),
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": k1_ms,
             "refractory_ms": k2_ms,
         },
     }
-
     if onset:
-        # a full FFT per frame is bounded by f32 vector throughput as well: 2.5 N log2 N flops per real FFT
-        # against the packed-FMA vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2 at 2.4 GHz)
-        flops = streams * n_cb * 2.5 * nfft * (nfft.bit_length() - 1)
-        peak_tflops = 256 * 4 * 16 * 2 * 2 * 2.4e9 / 1e12
-        result["roofline"]["valu"] = {"achieved": flops / (k1_ms * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s",
-                                      "frac": flops / (k1_ms * 1e-3) / 1e12 / peak_tflops,
-                                      "flops_per_frame": 2.5 * nfft * (nfft.bit_length() - 1)}
-    if result["roofline"].get("note") is None:
-        result["roofline"].pop("note", None)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb = cpu_baseline(bd, kind_name, samples, n, L, sr, min(args.cpu_streams, streams), nfft=nfft)
-        # the GPU's count over the same streams (equal counts are a full-size consistency check, not the parity test)
-        cb["gpu_events_same_sample"] = int(count[:cb.pop("_n")].sum().item())
-        result["cpu_baseline"] = cb
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        result["roofline"]["note"] = ("this kernel is limited by f32 VALU issue (a 2048-point FFT per 1024 new samples), "
+                                      "not by HBM; the HBM fraction is reported for comparison with the other workloads")
+        result["roofline"]["valu"] = _valu_roofline(streams, n_cb, nfft, k1_ms)
+    state = dict(kind_name=kind_name, samples=samples, values=values, flags=flags, count=count, idx=idx, ms=ms, n=n, L=L,
+                 sr=sr, nfft=nfft, streams=streams, out_stride=out_stride)
+    return result, state
+
+
+def _valu_roofline(streams, n_frames, nfft, k_ms):
+    # a full FFT per frame is bounded by f32 vector throughput as well: 2.5 N log2 N flops per real FFT
+    # against the packed-FMA vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 x 2 at 2.4 GHz)
+    flops = streams * n_frames * 2.5 * nfft * (nfft.bit_length() - 1)
+    peak_tflops = 256 * 4 * 16 * 2 * 2 * 2.4e9 / 1e12
+    return {"achieved": flops / (k_ms * 1e-3) / 1e12, "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": flops / (k_ms * 1e-3) / 1e12 / peak_tflops, "flops_per_frame": 2.5 * nfft * (nfft.bit_length() - 1)}
 
 
 def _pmc_traffic(workload, streams, seconds):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-    PMC passes of this same command (profiles/), or None."""
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The figure is not
+    measured in this run: it is replayed from the committed rocprofv3 PMC passes of this same command."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         e = t.get(workload)
         if e and e.get("streams") == streams and e.get("seconds") == seconds:
-            return e.get("hbm_bytes_per_launch")
+            return e.get("hbm_bytes_per_launch"), ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                                   "(%s), not measured in this run" % e.get("source", "profiles/"))
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline(bd, kind_name, samples, n, L, sr, n_streams, nfft=0):
+# --------------------------------------------------------------------------------------------
+# one GPU's share of the 131,072-track job: chunked executor, samples never resident at once
+# --------------------------------------------------------------------------------------------
+def run_chunked_onset(ctx, steps, warmup, tracks=0, seconds=0, chunk=0):
+    import ctypes
+    torch, bd = ctx.torch, ctx.bd
+    workload = "onset_2048_chunked"
+    _, hop, d_tracks, d_seconds, desc = WORKLOADS[workload]
+    tracks = tracks or d_tracks
+    seconds = seconds or d_seconds
+    chunk = min(chunk or 4096, tracks)
+    nfft = ONSET_FFT[workload]
+    n = SR * seconds
+    p = bd.OnsetParams.default(fft_len=nfft, hop=hop)
+    n_frames = bd.onset_frames(n, nfft, hop)
+    max_onsets = max(1, (n * 1000 // SR) // max(p.min_gap_ms, 1) + 1)
+    first = ctx.first_stream(tracks)
+    ex = bd.ChunkedExecutor(chunk, n)
+    count = torch.zeros((tracks,), dtype=torch.int32, device=ctx.dev)
+    frame = torch.zeros((tracks, max_onsets), dtype=torch.int32, device=ctx.dev)
+    ms = torch.zeros((tracks, max_onsets), dtype=torch.int32, device=ctx.dev)
+
+    def step():
+        ex.onset(SR, tracks, count, frame, ms, params=p, first_stream=first, seed=SEED)
+
+    for _ in range(max(warmup, 1)):
+        step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    main_ms, post_ms = ex.last_timing()            # the chunks of the last timed pass
+    k_ms = sum(main_ms) / max(len(main_ms), 1)
+    total = ctx.sum_over_ranks(int(count.sum().item()))
+    elapsed, k_ms = ctx.max_over_ranks(elapsed, k_ms)
+    dev_bytes = ex.device_bytes()
+    n_chunks = (tracks + chunk - 1) // chunk
+    alg_bytes = chunk * (((n_frames - 1) * hop + nfft) * 2 + n_frames * 4) if n_frames else 0   # per launch = per chunk
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+    result = {
+        "workload": workload,
+        "metric": "audio-sec analysed/sec (node), %d-pt STFT" % nfft,
+        "value": ctx.world * tracks * (n / SR) * steps / elapsed,
+        "unit": "audio-sec/s",
+        "n_gpus": ctx.world,
+        "steps": steps,
+        "ms_per_step": elapsed / steps * 1e3,
+        "scaling": "weak",
+        "config": {"workload": desc, "tracks_per_gpu": tracks, "seconds_per_track": seconds, "chunk_tracks": chunk,
+                   "chunks_per_pass": n_chunks, "frames_per_track": n_frames, "device_bytes_held": dev_bytes,
+                   "samples_bytes_per_pass": tracks * n * 2, "onsets_found": total, "seed": SEED,
+                   "timed_region": "whole pass: on-device synthesis of every chunk (side stream, overlapped) + STFT/flux + "
+                                   "peak picking; the samples of a pass never exist at once"},
+        "roofline": {"bound": "hbm", "kernel": "bd_stft_flux_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
+                     "peak_picking_ms": sum(post_ms) / max(len(post_ms), 1),
+                     "kernel_ms_per_chunk": [round(x, 3) for x in main_ms],
+                     "note": "VALU-issue bound (a 2048-point f32 FFT per 1024 new samples); launches overlap the synthesis "
+                             "of the next chunk",
+                     "valu": _valu_roofline(chunk, n_frames, nfft, k_ms) if k_ms else None},
+    }
+    ex.close()
+    del count, frame, ms
+    return result
+
+
+# --------------------------------------------------------------------------------------------
+# live path: 256 concurrent streams, one tick = one 1024-sample callback per stream
+# --------------------------------------------------------------------------------------------
+def run_live(ctx, ticks=400, streams=256, L=1024):
+    import numpy as np
+    bd = ctx.bd
+    out = {"workload": "live_256", "streams": streams, "callback_len": L, "ticks": ticks,
+           "tick_period_us": L / SR * 1e6,
+           "measured": "submit -> result on the host, per tick (pinned ring, one HIP graph replay per tick)"}
+    x = bd.synth_fill_host(streams, L * 64, seed=11)
+    wins = [np.ascontiguousarray(x[:, i * L:(i + 1) * L]) for i in range(64)]
+    for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
+        live = bd.Live(kind, SR, streams, max_callback_len=L, depth=4)
+        lat = []
+        for t in range(ticks):                     # every tick counts: the first ones included
+            t0 = time.perf_counter()
+            tick = live.submit(wins[t % 64])
+            live.poll(tick)
+            lat.append((time.perf_counter() - t0) * 1e6)
+        live.close()
+        lat = np.array(lat)
+        out[kind.name] = {"p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)),
+                          "max_us": float(lat.max()), "first_tick_us": float(lat[0])}
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on this host's cores
+# --------------------------------------------------------------------------------------------
+def _host_cpus():
+    """(threads to use, description of the host's CPUs)."""
+    total = os.cpu_count() or 1
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except Exception:
+        allowed = total
+    use = allowed
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    note = "all CPUs this process may run on"
+    if share.isdigit() and 0 < int(share) < use:
+        # a job on a shared machine gets a CPU share; the harness publishes it in OMP_NUM_THREADS
+        use = int(share)
+        note = f"the job's CPU share (OMP_NUM_THREADS={share}) of a host with {total} logical CPUs"
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return use, {"cpu_model": model, "cores_total": total, "cores_allowed": allowed, "cores_used": use, "cores_note": note}
+
+
+def cpu_baseline(ctx, state, n_streams):
     """The CPU restatement of the reference (oracle/, a port: the Rust original
-    cannot be built here) on the first `n_streams` streams of the same batch."""
+    cannot be built here) on the first `n_streams` streams of the same batch,
+    compared with the GPU's results stream by stream."""
+    import numpy as np
+    kind_name = state["kind_name"]
     if kind_name == "Onset":
-        return cpu_baseline_onset(samples, n, L, nfft, sr, min(n_streams, 128))
+        return cpu_baseline_onset(state, min(n_streams, 128))
     if kind_name == "Biquad":
-        return cpu_baseline_biquad(samples, n, L, sr, min(n_streams, 512))
+        return cpu_baseline_biquad(state, min(n_streams, 512))
     from oracle import bd_oracle
     okind = bd_oracle.KIND_SPECTRUM if kind_name == "Spectrum" else bd_oracle.KIND_LPF
-    host = samples[:n_streams, :n].cpu().numpy()
-    cores = 16
-    try:
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    except Exception:
-        pass
+    n, L, sr = state["n"], state["L"], state["sr"]
+    n_streams = min(n_streams, state["streams"])
+    host = state["samples"][:n_streams, :n].cpu().numpy()
+    cores, info = _host_cpus()
     t0 = time.perf_counter()
-    total, _ = bd_oracle.run_batch(okind, sr, host, L, n_threads=cores)
+    total, counts = bd_oracle.run_batch(okind, sr, host, L, n_threads=cores)
     dt = time.perf_counter() - t0
     one = max(1, n_streams // (cores * 2))
     t1 = time.perf_counter()
     bd_oracle.run_batch(okind, sr, host[:one], L, n_threads=1)
     dt1 = time.perf_counter() - t1
-    return {
+    gpu_counts = state["count"][:n_streams].cpu().numpy().astype(np.int64)
+    differing = np.nonzero(gpu_counts != counts.astype(np.int64))[0]
+    out = {
         "value": n_streams * (n / sr) / dt,
         "unit": "audio-sec/s",
         "cores": cores,
         "kind": "port",
+        "label": "CPU restatement of the reference (oracle/), not the Rust original",
         "sample": f"first {n_streams} streams x {n // sr} s of the same batch, {cores} threads "
                   f"(one contiguous stream shard each), {dt:.1f} s of wall time; beats found {total}",
         "cpu_events": int(total),
-        "_n": n_streams,
+        "gpu_events_same_sample": int(gpu_counts.sum()),
+        "streams_compared": int(n_streams),
+        "streams_differing": int(len(differing)),
+        "streams_differing_list": [int(s) for s in differing[:64]],
         "value_1core": one * (n / sr) / dt1,
         "sample_1core": f"first {one} streams, 1 thread, {dt1:.1f} s",
     }
+    out.update(info)
+    if kind_name == "Spectrum":
+        out.update(_threshold_adjacent(ctx, state, host, n_streams, bd_oracle))
+    return out
 
 
-def cpu_baseline_biquad(samples, n, L, sr, n_streams):
+def _threshold_adjacent(ctx, state, host, n_streams, bd_oracle, rel=1e-4, threshold=2.1e6):
+    """The callbacks of the compared streams whose reference value lies within `rel` of the decision
+    threshold: the only ones whose decision may differ between the f32 FFT of the CPU restatement and the
+    pruned DFT of the kernel.  Candidates are taken from the GPU values with twice the margin (values agree
+    to `rel`), then the oracle's own value decides membership."""
+    import numpy as np
+    torch = ctx.torch
+    n, L = state["n"], state["L"]
+    n_cb = n // L
+    vals = state["values"][:n_streams, :n_cb]
+    near = torch.nonzero((vals - threshold).abs() <= 2 * rel * threshold).cpu().numpy()
+    listed = []
+    for s, j in near:
+        end = (int(j) + 1) * L
+        ring = np.zeros(1024, dtype=np.float32)          # ring pre-filled with zeros, spectrum.rs:50-51
+        lo = max(0, end - 1024)
+        ring[1024 - (end - lo):] = host[s, lo:end]
+        ref, _ = bd_oracle.spectrum_band_max(ring, state["sr"])
+        if abs(ref - threshold) <= rel * threshold:
+            g = float(vals[s, j])
+            listed.append({"stream": int(s), "callback": int(j), "oracle_value": ref, "gpu_value": g,
+                           "oracle_decision_value_above": bool(ref > threshold), "gpu_decision_value_above": bool(g > threshold)})
+    return {"threshold_adjacent_callbacks": listed[:64], "threshold_adjacent_count": len(listed),
+            "threshold_adjacent_rule": f"|oracle value - {threshold:g}| <= {rel:g} * {threshold:g}, over "
+                                       f"{n_streams} streams x {n_cb} callbacks"}
+
+
+def cpu_baseline_biquad(state, n_streams):
     """The CPU definition of the carried-state biquad envelope (oracle/bd_oracle_ext.c)
     plus the refractory replay, one stream per task."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import bd_oracle, bd_oracle_ext as ox
-    host = samples[:n_streams, :n].cpu().numpy()
-    cores = 16
-    try:
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    except Exception:
-        pass
+    n, L, sr = state["n"], state["L"], state["sr"]
+    host = state["samples"][:n_streams, :n].cpu().numpy()
+    cores, info = _host_cpus()
     p = ox.biquad_params(window_len=L)
     d = ox.biquad_design(sr, p.cutoff_hz, p.q_factor)
     ol = bd_oracle.lib()
@@ -375,31 +588,20 @@ def cpu_baseline_biquad(samples, n, L, sr, n_streams):
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(one, host))
+        per_stream = list(ex.map(one, host))
     dt = time.perf_counter() - t0
-    return {
-        "value": n_streams * (n / sr) / dt,
-        "unit": "audio-sec/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": f"first {n_streams} streams x {n // sr} s of the same batch, {cores} threads, {dt:.1f} s of wall "
-                  f"time; beats found {total} (the definition of the extension analysis; refractory replay in Python)",
-        "cpu_events": int(total),
-        "_n": n_streams,
-    }
+    return _ext_baseline(state, n_streams, per_stream, dt, cores, info,
+                         "the definition of the extension analysis; refractory replay in Python")
 
 
-def cpu_baseline_onset(samples, n, hop, nfft, sr, n_streams):
+def cpu_baseline_onset(state, n_streams):
     """The CPU definition of the extension analysis (oracle/bd_oracle_ext.c) on the
     first `n_streams` tracks; ctypes releases the GIL, one track per task."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import bd_oracle_ext as ox
-    host = samples[:n_streams, :n].cpu().numpy()
-    cores = 16
-    try:
-        cores = max(1, min(16, len(os.sched_getaffinity(0))))
-    except Exception:
-        pass
+    n, hop, sr, nfft = state["n"], state["L"], state["sr"], state["nfft"]
+    host = state["samples"][:n_streams, :n].cpu().numpy()
+    cores, info = _host_cpus()
     p = ox.default_params(fft_len=nfft, hop=hop)
 
     def one(row):
@@ -408,18 +610,109 @@ def cpu_baseline_onset(samples, n, hop, nfft, sr, n_streams):
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(one, host))
+        per_stream = list(ex.map(one, host))
     dt = time.perf_counter() - t0
-    return {
+    return _ext_baseline(state, n_streams, per_stream, dt, cores, info,
+                         "scalar radix-2 FFT: the definition of the analysis, not a tuned CPU FFT")
+
+
+def _ext_baseline(state, n_streams, per_stream, dt, cores, info, what):
+    import numpy as np
+    n, sr = state["n"], state["sr"]
+    gpu = state["count"][:n_streams].cpu().numpy().astype(np.int64)
+    differing = np.nonzero(gpu != np.asarray(per_stream, dtype=np.int64))[0]
+    out = {
         "value": n_streams * (n / sr) / dt,
         "unit": "audio-sec/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"first {n_streams} tracks x {n // sr} s of the same batch, {cores} threads, {dt:.1f} s of wall "
-                  f"time; onsets found {total} (scalar radix-2 FFT: the definition of the analysis, not a tuned CPU FFT)",
-        "cpu_events": int(total),
-        "_n": n_streams,
+        "label": "CPU definition of an extension analysis (no reference counterpart)",
+        "sample": f"first {n_streams} streams x {n // sr} s of the same batch, {cores} threads, {dt:.1f} s of wall "
+                  f"time; events found {sum(per_stream)} ({what})",
+        "cpu_events": int(sum(per_stream)),
+        "gpu_events_same_sample": int(gpu.sum()),
+        "streams_compared": int(n_streams),
+        "streams_differing": int(len(differing)),
+        "streams_differing_list": [int(s) for s in differing[:64]],
     }
+    out.update(info)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="spectrum_hop512", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=0, help="override streams per GPU (testing only)")
+    ap.add_argument("--seconds", type=int, default=0, help="override stream length in seconds (testing only)")
+    ap.add_argument("--chunk-tracks", type=int, default=0, help="chunked workload: tracks per chunk (default 4096)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-streams", type=int, default=1024, help="streams in the CPU baseline sample")
+    ap.add_argument("--also", default="auto", choices=["auto", "all", "config4", "none"],
+                    help="extra short measurements attached as `also` (auto: all at N = 1 with the default workload, "
+                         "the chunked 131,072-track share at N > 1)")
+    ap.add_argument("--also-tracks", type=int, default=0, help="tracks per GPU of the chunked `also` entry (rehearsals)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for the barrier / timing reduction (gloo: rehearsals)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (a box with one GPU)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU work: every rank joins a gloo group, the ranks' numbers are summed and rank 0 prints "
+                         "them (checks the launcher on a machine without a GPU)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))        # nothing above touched the GPU
+
+    if args.rehearse_launch:
+        return rehearse_launch(args)
+    ctx = Ctx(args)
+    torch = ctx.torch
+    chunked = WORKLOADS[args.workload][0] == "OnsetChunked"
+    if chunked:
+        r = run_chunked_onset(ctx, args.steps, args.warmup, args.streams, args.seconds, args.chunk_tracks)
+        r.update({"warmup": args.warmup, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
+        r.pop("workload")
+        result, state = r, None
+    else:
+        result, state = run_resident(ctx, args.workload, args.steps, args.warmup, args.streams, args.seconds)
+        if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(ctx, state, args.cpu_streams)
+
+    also_mode = args.also
+    if also_mode == "auto":
+        if args.workload != "spectrum_hop512" or args.streams or args.seconds:
+            also_mode = "none"
+        else:
+            also_mode = "all" if ctx.world == 1 else "config4"
+    if also_mode != "none":
+        state = None
+        torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()                   # the chunked pass needs 217 GB of the 288
+        also = []
+        if also_mode == "all":
+            for w in ("spectrum_1024", "lpf", "biquad", "onset_2048"):
+                r, st_ = run_resident(ctx, w, 3, 1)
+                del st_
+                gc.collect()
+                torch.cuda.empty_cache()
+                also.append({"workload": w, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                             "steps": 3, "description": r["config"]["workload"], "events_found": r["config"]["beats_found"],
+                             "roofline": r["roofline"]})
+        also.append(run_chunked_onset(ctx, 2, 1, tracks=args.also_tracks, chunk=args.chunk_tracks))
+        if also_mode == "all" and ctx.rank == 0:
+            also.append(run_live(ctx))
+        result["also"] = also
+    if ctx.rank == 0:
+        print(json.dumps(result), flush=True)
+    if ctx.dist is not None:
+        ctx.dist.barrier()
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

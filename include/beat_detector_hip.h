@@ -354,6 +354,61 @@ int bd_biquad_envelope(uint32_t sampling_rate, const bd_biquad_params *params, c
                        const int16_t *samples, uint64_t n_streams, uint64_t n_samples, uint64_t stream_stride,
                        float *values, uint8_t *flags, uint64_t out_stride, void *hip_stream);
 
+/* ---- chunked executor: shards larger than device memory (new) ----------- */
+/* One GPU's share of a stream-sharded job may exceed its memory (131,072
+ * five-minute tracks over 8 GPUs: 433 GB of samples per GPU).  The executor
+ * cuts the shard into chunks of `chunk_streams` streams, keeps two sample
+ * buffers of one chunk each on the device, and has a *source* fill chunk c + 1
+ * on its own side stream while chunk c is analysed on the caller's stream.
+ * Streams are independent (one AnalysisState and one ring per detector:
+ * src/strategies/mod.rs:39-56, src/strategies/spectrum.rs:38-44), so chunking
+ * changes no result: stream s gets exactly the beats / onsets of
+ * bd_analyze_batch / bd_onset_batch over the whole shard.
+ *
+ * A source enqueues, on `hip_stream`, whatever puts the samples of streams
+ * [first_stream, first_stream + n_streams) of the shard into rows of `dst`
+ * (device, row pitch `stream_stride` samples): a generator kernel, or copies
+ * from pinned host memory after a decode.  It may block the host; it must not
+ * synchronise the device.  Returns BD_OK or a negative status (ends the pass). */
+typedef int (*bd_chunk_source_fn)(void *user, int16_t *dst, uint64_t first_stream, uint64_t n_streams,
+                                  uint64_t n_samples, uint64_t stream_stride, void *hip_stream);
+/* The synthetic click-track generator as a source (user = const bd_synth_source *):
+ * stream s of the shard is stream first_stream + s of bd_synth_fill. */
+typedef struct bd_synth_source {
+    uint64_t seed;
+    uint64_t first_stream;
+    uint32_t sampling_rate;
+} bd_synth_source;
+int bd_chunk_source_synth(void *user, int16_t *dst, uint64_t first_stream, uint64_t n_streams,
+                          uint64_t n_samples, uint64_t stream_stride, void *hip_stream);
+
+typedef struct bd_chunked bd_chunked;
+/* Allocates the two sample buffers (chunk_streams rows of n_samples, rows on
+ * 128-byte lines), the side stream and the events on `device` (< 0: current). */
+int bd_chunked_create(uint64_t chunk_streams, uint64_t n_samples, int device, bd_chunked **out);
+/* Device memory the executor holds at the moment. */
+uint64_t bd_chunked_device_bytes(const bd_chunked *ex);
+/* bd_analyze_batch over n_streams streams delivered by `source`; beat_count /
+ * beat_idx / beat_ms are device arrays over all n_streams ([n_streams],
+ * [n_streams][max_beats]).  Enqueues the whole pass and returns; the results are
+ * complete when `hip_stream` has drained.  The first pass of a given analysis
+ * allocates the chunk's intermediate buffer, later passes allocate nothing. */
+int bd_chunked_analyze(bd_chunked *ex, int kind, uint32_t sampling_rate, const bd_params *params,
+                       uint32_t callback_len, bd_chunk_source_fn source, void *user, uint64_t n_streams,
+                       uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, uint32_t max_beats,
+                       void *hip_stream);
+/* bd_onset_batch (extension analysis) the same way. */
+int bd_chunked_onset(bd_chunked *ex, uint32_t sampling_rate, const bd_onset_params *p,
+                     bd_chunk_source_fn source, void *user, uint64_t n_streams,
+                     uint32_t *onset_count, uint32_t *onset_frame, uint32_t *onset_ms, uint32_t max_onsets,
+                     void *hip_stream);
+/* Per chunk of the last pass: milliseconds of its dominant kernel (strategy / STFT)
+ * and of the pass after it (refractory rule / peak picking), from events on the
+ * caller's stream.  Waits for those chunks; returns the number of chunks of the
+ * pass (the first `capacity` are written; either array may be NULL) or < 0. */
+int bd_chunked_last_timing(bd_chunked *ex, float *main_ms, float *post_ms, uint32_t capacity);
+void bd_chunked_destroy(bd_chunked *ex);
+
 /* ---- instrumentation --------------------------------------------------- */
 /* Name and grid of the dominant kernel of the last bd_analyze_batch call on
  * this thread (for profilers). */
