@@ -333,11 +333,15 @@ struct bd_host_job {
 #define BD_HOST_CHUNK_BYTES (256ull << 20)
 #define BD_HOST_PACK_THREADS 8
 
+// device workers of one bd_analyze_batch_multi call share the host's packing threads
+static thread_local unsigned bd_host_pack_share = 1;
+
 static void bd_host_pack(int16_t *dst, uint64_t d_stride, const int16_t *src, uint64_t stride, uint64_t n_samples,
                          uint64_t rows)
 {
     const char *env = getenv("BD_HOST_THREADS"); // tuning knob
-    const unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : BD_HOST_PACK_THREADS;
+    unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : BD_HOST_PACK_THREADS;
+    want = want / bd_host_pack_share ? want / bd_host_pack_share : 1;
     const unsigned n_thr = rows >= 4 * want ? want : 1;
     auto work = [=](unsigned t) {
         for (uint64_t r = rows * t / n_thr; r < rows * (t + 1) / n_thr; r++)
@@ -454,7 +458,28 @@ extern "C" int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd
                                       uint32_t max_beats, const int *devices, int n_devices)
 {
     if (!devices || n_devices <= 0) { bd_set_error("bd_analyze_batch_multi: empty device list"); return BD_ERR_INVALID_ARG; }
+    // argument errors are reported once, here, before any worker starts or any pointer is offset
+    {
+        bd_plan plan;
+        const int s = bd_make_plan(kind, sampling_rate, params, &plan);
+        if (s != BD_OK) return s;
+    }
+    if (!samples || !beat_count) { bd_set_error("samples and beat_count must not be NULL"); return BD_ERR_INVALID_ARG; }
     if (callback_len == 0) { bd_set_error("callback_len must be >= 1"); return BD_ERR_EMPTY_WINDOW; }
+    if (stream_stride < n_samples) { bd_set_error("stream_stride < n_samples"); return BD_ERR_INVALID_ARG; }
+    if (n_streams == 0) return BD_OK;
+    {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            bd_set_error("no HIP device available (this library has no CPU path)");
+            return BD_ERR_NO_DEVICE;
+        }
+        for (int g = 0; g < n_devices; g++)
+            if (devices[g] < 0 || devices[g] >= count) {
+                bd_set_error("device %d out of range (%d devices)", devices[g], count);
+                return BD_ERR_INVALID_ARG;
+            }
+    }
     const uint64_t n_cb = n_samples / callback_len;
     std::vector<int> status((size_t)n_devices, BD_OK);
     std::vector<std::string> messages((size_t)n_devices);
@@ -465,6 +490,7 @@ extern "C" int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd
         const uint64_t s1 = n_streams * (uint64_t)(g + 1) / (uint64_t)n_devices;
         workers.emplace_back([=, &status, &messages] {
             if (s1 == s0) return;
+            bd_host_pack_share = (unsigned)n_devices;
             status[(size_t)g] = bd_analyze_batch_host(
                 kind, sampling_rate, params, samples + s0 * stream_stride, s1 - s0, n_samples,
                 stream_stride, callback_len,

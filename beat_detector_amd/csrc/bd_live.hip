@@ -37,10 +37,18 @@ struct bd_live_result {
     uint32_t candidate;     // decision before the refractory rule (0 when not evaluated)
 };
 
+// What changes from tick to tick, in pinned host memory that the kernels read through its
+// device address: a captured graph never has to be rebuilt or updated for a new callback length.
+struct bd_live_ctl {
+    uint32_t n;             // samples per stream in this tick
+    uint32_t reserved;
+};
+
 struct bd_live_args {
     const int16_t  *in;     // [M][in_stride]
     uint64_t        in_stride;
-    uint32_t        n;      // samples per stream in this callback
+    uint32_t        n;      // samples per stream in this callback (ctl == NULL)
+    const bd_live_ctl *ctl; // if set: n = in_stride = ctl->n
     int16_t        *ring;   // [M][1024]
     bd_live_state  *state;  // [M]
     bd_live_result *result; // [M]
@@ -72,28 +80,53 @@ __device__ float bd_block_max(float v, float *red)
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-#define BD_LIVE_LPF_STAGE 2048
+#define BD_LIVE_STAGE 2048
+
+// Copies samples [base, base + cnt) of a callback into LDS: 16-byte loads (the input may sit in
+// pinned host memory, where every request crosses PCIe) at 2-byte-aligned addresses, the last
+// cnt % 8 samples one by one.  Callers synchronise.
+__device__ __forceinline__ void bd_live_stage_chunk(const int16_t *in, uint32_t base, uint32_t cnt, uint4 *stage)
+{
+    typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+    const uint32_t units = cnt / 8;
+    for (uint32_t u = threadIdx.x; u < units; u += 256) {
+        const u32x4_a2 v = *reinterpret_cast<const u32x4_a2 *>(in + base + 8 * u);
+        stage[u] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+    int16_t *s16 = reinterpret_cast<int16_t *>(stage);
+    for (uint32_t i = 8 * units + threadIdx.x; i < cnt; i += 256) s16[i] = in[base + i];
+}
 
 __global__ __launch_bounds__(256) void bd_live_tick_kernel(bd_live_args a)
 {
     __shared__ float red[4];
-    __shared__ int16_t stage[BD_LIVE_LPF_STAGE];
+    __shared__ uint4 stage_u4[BD_LIVE_STAGE / 8];
     __shared__ uint32_t sh_allowed;
+    const int16_t *stage = reinterpret_cast<const int16_t *>(stage_u4);
     const uint32_t m = blockIdx.x, tid = threadIdx.x;
-    const int16_t *in = a.in + (uint64_t)m * a.in_stride;
+    const uint32_t n = a.ctl ? a.ctl->n : a.n;
+    const uint64_t in_stride = a.ctl ? (uint64_t)n : a.in_stride;
+    const int16_t *in = a.in + (uint64_t)m * in_stride;
     int16_t *ring = a.ring + (uint64_t)m * BD_RING_LEN;
     bd_live_state st = a.state[m];
-    const uint32_t n = a.n;
     const bd_plan &pl = a.plan;
 
-    uint32_t new_head = st.head;
-    if (pl.kind == BD_KIND_SPECTRUM) {
-        // spectrum.rs:65-68: push every sample, overwriting the oldest
-        const uint32_t skip = n > BD_RING_LEN ? n - BD_RING_LEN : 0;
-        for (uint32_t i = skip + tid; i < n; i += 256)
-            ring[(st.head + i) & (BD_RING_LEN - 1)] = in[i];
-        new_head = (st.head + n) & (BD_RING_LEN - 1);
+    // one pass over the callback through LDS: window_stats.rs:41-55 over the callback's own
+    // samples, and (Spectrum) spectrum.rs:65-68: push every sample, overwriting the oldest
+    const uint32_t skip = n > BD_RING_LEN ? n - BD_RING_LEN : 0;
+    float amax = 0.f;
+    for (uint32_t base = 0; base < n; base += BD_LIVE_STAGE) {
+        const uint32_t cnt = (n - base < BD_LIVE_STAGE) ? n - base : BD_LIVE_STAGE;
+        if (base) __syncthreads();
+        bd_live_stage_chunk(in, base, cnt, stage_u4);
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            const int16_t v = stage[i];
+            amax = fmaxf(amax, fabsf((float)v));
+            if (pl.kind == BD_KIND_SPECTRUM && base + i >= skip) ring[(st.head + base + i) & (BD_RING_LEN - 1)] = v;
+        }
     }
+    const uint32_t new_head = pl.kind == BD_KIND_SPECTRUM ? (st.head + n) & (BD_RING_LEN - 1) : st.head;
     // spectrum.rs:71 / lpf.rs:54: update_time (mod.rs:76-84)
     const float ms_of_frame = pl.ms_per_sample * (float)n;
     const uint32_t beat_time = st.time_ms + bd_dev_f32_as_u32(ms_of_frame / 2.0f);
@@ -102,9 +135,6 @@ __global__ __launch_bounds__(256) void bd_live_tick_kernel(bd_live_args a)
     bool allowed = true;
     if (beat_time > 0 && beat_time < st.last_beat + pl.gap_ms) allowed = false;
 
-    // window_stats.rs:41-55 over the callback's own samples
-    float amax = 0.f;
-    for (uint32_t i = tid; i < n; i += 256) amax = fmaxf(amax, fabsf((float)in[i]));
     amax = fminf(bd_block_max(amax, red), 32767.f);
     const bool gate = amax >= (float)pl.min_amp;       // lib.rs:133-136
 
@@ -139,14 +169,18 @@ __global__ __launch_bounds__(256) void bd_live_tick_kernel(bd_live_args a)
             }
             value = (pl.divisor == 0.f) ? best : best / pl.divisor;   // divide_by_N
             candidate = value > pl.threshold;                          // spectrum.rs:92
-        } else if (pl.alpha_valid) {
-            // lpf.rs:66-75; the recurrence is serial, thread 0 walks it over LDS
+        } else {
+            // lpf.rs:66-75; the recurrence is serial, thread 0 walks it over LDS.  A NaN alpha
+            // (sampling rate 0 as u16) turns every filtered sample into 0 in the reference
+            // (`NaN as i16`); here y becomes NaN and the maximum, which skips NaNs, stays 0.
             float y = 0.f, ymax = 0.f;
-            for (uint32_t base = 0; base < n; base += BD_LIVE_LPF_STAGE) {
-                const uint32_t cnt = (n - base < BD_LIVE_LPF_STAGE) ? n - base : BD_LIVE_LPF_STAGE;
-                __syncthreads();
-                for (uint32_t i = tid; i < cnt; i += 256) stage[i] = in[base + i];
-                __syncthreads();
+            for (uint32_t base = 0; base < n; base += BD_LIVE_STAGE) {
+                const uint32_t cnt = (n - base < BD_LIVE_STAGE) ? n - base : BD_LIVE_STAGE;
+                if (n > BD_LIVE_STAGE) { // longer than the staging buffer: it holds the last chunk, fetch again
+                    __syncthreads();
+                    bd_live_stage_chunk(in, base, cnt, stage_u4);
+                    __syncthreads();
+                }
                 if (tid == 0) {
                     for (uint32_t i = 0; i < cnt; i++) {
                         const float xx = (float)stage[i];
@@ -283,7 +317,7 @@ extern "C" int bd_detector_is_beat(bd_detector *d, const int16_t *samples, size_
     if (s == BD_OK) {
         memcpy(d->h_in, samples, n * sizeof(int16_t));
         bd_live_args a;
-        a.in = d->d_in; a.in_stride = d->in_cap; a.n = (uint32_t)n;
+        a.in = d->d_in; a.in_stride = d->in_cap; a.n = (uint32_t)n; a.ctl = nullptr;
         a.ring = d->d_ring; a.state = d->d_state; a.result = d->d_result; a.plan = d->plan;
         s = bd_check_hip(hipMemcpyAsync(d->d_in, d->h_in, n * sizeof(int16_t), hipMemcpyHostToDevice, d->stream), "copy callback to device");
         if (s == BD_OK) {
@@ -317,23 +351,24 @@ extern "C" int bd_detector_last(const bd_detector *d, float *value, int *candida
 // Multi-stream live engine: the successor of record::start_listening's callback
 // loop (src/record.rs:87-146) for M concurrent streams.  Every tick carries one
 // callback of n samples for each stream.  Ticks go through a ring of K slots
-// (pinned host staging, device staging, device and pinned result buffers); a
-// tick is one replay of a captured HIP graph: host-to-device copy, optional
-// ingest conversion (record.rs:151-166), the live kernel, device-to-host copy
-// of the results.  All ticks run on one stream, in order, so detector state
+// (pinned host staging, pinned control block, pinned result buffer); a tick is
+// one replay of a HIP graph captured when the engine was created: optional
+// ingest conversion (record.rs:151-166) and the live kernel, both working on the
+// pinned buffers in place.  All ticks run on one stream, in order, so detector state
 // advances exactly as in the reference.  If an on_beat callback is installed a
 // dispatcher thread calls it in tick order, stream order, off the submitting
 // thread (the reference runs on_beat_cb on the audio thread: record.rs:96).
 // =============================================================================
 #include <atomic>
 #include <condition_variable>
-#include <map>
 #include <mutex>
 #include <thread>
-#include <tuple>
 
-__global__ void bd_live_convert_kernel(const void *in, int16_t *out, uint64_t n, int format)
+// Ingest conversion of one tick (record.rs:151-166); the grid is sized for the longest callback,
+// the tick's own length comes from the control block.
+__global__ void bd_live_convert_kernel(const void *in, int16_t *out, const bd_live_ctl *ctl, uint32_t n_streams, int format)
 {
+    const uint64_t n = (uint64_t)n_streams * ctl->n;
     const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (format == BD_FMT_U16) {
@@ -347,22 +382,20 @@ __global__ void bd_live_convert_kernel(const void *in, int16_t *out, uint64_t n,
 }
 
 struct bd_live_slot {
-    void           *h_in = nullptr;     // pinned, M * max_len * 4 bytes
-    void           *d_raw = nullptr;    // device copy of h_in
+    void           *h_in = nullptr;     // pinned, M * max_len * 4 bytes; the kernels read it in place
+    bd_live_ctl    *h_ctl = nullptr;    // pinned: this tick's callback length
     int16_t        *d_i16 = nullptr;    // converted samples (unused for i16 input)
-    bd_live_result *d_res = nullptr;    // [M]
-    bd_live_result *h_res = nullptr;    // pinned [M]
+    bd_live_result *h_res = nullptr;    // pinned [M]; the kernel writes it in place
     hipEvent_t      done = nullptr;
     uint64_t        tick = 0;           // tick currently in the slot (valid if busy)
     bool            busy = false;
-    std::map<std::tuple<uint32_t, int>, hipGraphExec_t> graphs; // (n, format) -> graph
+    hipGraphExec_t  graph[3] = {nullptr, nullptr, nullptr}; // one per sample format, any callback length
 };
 
 struct bd_live {
     bd_plan        plan;
     int            device = 0;
     uint32_t       n_streams = 0, max_len = 0, depth = 0;
-    bool           zero_copy = true;     // kernels work on the pinned buffers directly
     hipStream_t    stream = nullptr;
     hipStream_t    cap_stream = nullptr; // graph capture only
     int16_t       *d_ring = nullptr;
@@ -377,7 +410,7 @@ struct bd_live {
     void          *on_beat_user = nullptr;
     std::thread    dispatcher;
     std::atomic<bool> stop{false};
-    int            dispatch_error = BD_OK;
+    std::atomic<int>  dispatch_error{BD_OK};
 };
 
 static void bd_live_release_locked(bd_live *L, bd_live_slot &s)
@@ -399,7 +432,13 @@ static void bd_live_dispatch_loop(bd_live *L)
             if (L->next_tick <= tick) return; // stopping and nothing left
             s = &L->slots[tick % L->depth];
         }
-        if (hipEventSynchronize(s->done) != hipSuccess) { L->dispatch_error = BD_ERR_HIP; return; }
+        if (hipEventSynchronize(s->done) != hipSuccess) {
+            // wake everyone who waits for a slot or a tick: they return the error
+            std::lock_guard<std::mutex> lk(L->mu);
+            L->dispatch_error.store(BD_ERR_HIP);
+            L->cv.notify_all();
+            return;
+        }
         for (uint32_t m = 0; m < L->n_streams; m++)
             if (s->h_res[m].beat) L->on_beat(L->on_beat_user, m, s->h_res[m].relative_ms);
         {
@@ -422,11 +461,10 @@ extern "C" void bd_live_destroy(bd_live *L)
     }
     if (L->stream) (void)hipStreamSynchronize(L->stream);
     for (auto &s : L->slots) {
-        for (auto &g : s.graphs) (void)hipGraphExecDestroy(g.second);
+        for (auto &g : s.graph) if (g) (void)hipGraphExecDestroy(g);
         if (s.h_in) (void)hipHostFree(s.h_in);
-        if (s.d_raw) (void)hipFree(s.d_raw);
+        if (s.h_ctl) (void)hipHostFree(s.h_ctl);
         if (s.d_i16) (void)hipFree(s.d_i16);
-        if (s.d_res) (void)hipFree(s.d_res);
         if (s.h_res) (void)hipHostFree(s.h_res);
         if (s.done) (void)hipEventDestroy(s.done);
     }
@@ -438,9 +476,48 @@ extern "C" void bd_live_destroy(bd_live *L)
     delete L;
 }
 
+// Captures the graph of one tick for this slot and sample format: [ingest conversion ->] tick
+// kernel.  The kernels read the pinned staging buffer and write the pinned result buffer through
+// their device addresses (no copy nodes) and take the callback length from the slot's control
+// block, so one graph serves every callback length and no tick ever pays for a capture.
+// Captured on a stream of its own: a thread may be waiting on an event of the working stream.
+static int bd_live_build_graph(bd_live *L, bd_live_slot &s, int format, hipGraphExec_t *out)
+{
+    const size_t M = L->n_streams;
+    hipGraph_t graph = nullptr;
+    void *dp_in = nullptr, *dp_res = nullptr, *dp_ctl = nullptr;
+    BD_HIP(hipHostGetDevicePointer(&dp_in, s.h_in, 0));
+    BD_HIP(hipHostGetDevicePointer(&dp_res, s.h_res, 0));
+    BD_HIP(hipHostGetDevicePointer(&dp_ctl, s.h_ctl, 0));
+    BD_HIP(hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeRelaxed));
+    const int16_t *in16 = (const int16_t *)dp_in;
+    if (format != BD_FMT_I16) {
+        const uint64_t most = (uint64_t)M * L->max_len;
+        dim3 grid;
+        (void)bd_grid_dims((most + 255) / 256, &grid);
+        hipLaunchKernelGGL(bd_live_convert_kernel, grid, dim3(256), 0, L->cap_stream,
+                           (const void *)dp_in, s.d_i16, (const bd_live_ctl *)dp_ctl, (uint32_t)M, format);
+        in16 = s.d_i16;
+    }
+    bd_live_args a;
+    a.in = in16; a.in_stride = 0; a.n = 0; a.ctl = (const bd_live_ctl *)dp_ctl;
+    a.ring = L->d_ring; a.state = L->d_state; a.result = (bd_live_result *)dp_res; a.plan = L->plan;
+    hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->cap_stream, a);
+    const hipError_t e = hipGetLastError();
+    const hipError_t e2 = hipStreamEndCapture(L->cap_stream, &graph);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return bd_check_hip(e != hipSuccess ? e : e2, "capture live tick graph");
+    }
+    const hipError_t e3 = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    return bd_check_hip(e3, "instantiate live tick graph");
+}
+
 static int bd_live_init(bd_live *L)
 {
     const size_t M = L->n_streams, cap = (size_t)L->max_len;
+    if ((uint64_t)M * cap > 0x7fffffffull) { bd_set_error("n_streams x max_callback_len too large"); return BD_ERR_UNSUPPORTED; }
     BD_HIP(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
     BD_HIP(hipStreamCreateWithFlags(&L->cap_stream, hipStreamNonBlocking));
     BD_HIP(hipMalloc((void **)&L->d_ring, M * BD_RING_LEN * sizeof(int16_t)));
@@ -450,13 +527,19 @@ static int bd_live_init(bd_live *L)
     L->slots.resize(L->depth);
     for (auto &s : L->slots) {
         BD_HIP(hipHostMalloc(&s.h_in, M * cap * 4, hipHostMallocDefault));
-        BD_HIP(hipMalloc(&s.d_raw, M * cap * 4));
+        BD_HIP(hipHostMalloc((void **)&s.h_ctl, sizeof(bd_live_ctl), hipHostMallocDefault));
         BD_HIP(hipMalloc((void **)&s.d_i16, M * cap * sizeof(int16_t)));
-        BD_HIP(hipMalloc((void **)&s.d_res, M * sizeof(bd_live_result)));
         BD_HIP(hipHostMalloc((void **)&s.h_res, M * sizeof(bd_live_result), hipHostMallocDefault));
         BD_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        s.h_ctl->n = 0; s.h_ctl->reserved = 0;
     }
     BD_HIP(hipStreamSynchronize(L->stream));
+    // every graph a tick can need exists before the first tick
+    for (auto &s : L->slots)
+        for (int format = 0; format < 3; format++) {
+            const int st = bd_live_build_graph(L, s, format, &s.graph[format]);
+            if (st != BD_OK) return st;
+        }
     return BD_OK;
 }
 
@@ -483,8 +566,6 @@ extern "C" int bd_live_create(int kind, uint32_t sampling_rate, const bd_params 
     if (!L) { bd_set_error("out of host memory"); return BD_ERR_HIP; }
     L->plan = plan; L->device = device; L->n_streams = n_streams; L->max_len = max_callback_len;
     L->depth = depth ? (depth > 64 ? 64 : depth) : 4;
-    const char *zc = getenv("BD_LIVE_ZERO_COPY");
-    L->zero_copy = !(zc && zc[0] == '0');
     if (device != prev) BD_HIP(hipSetDevice(device));
     s = bd_live_init(L);
     if (device != prev) (void)hipSetDevice(prev);
@@ -506,59 +587,12 @@ extern "C" int bd_live_set_on_beat(bd_live *L, bd_live_on_beat_fn cb, void *user
     return BD_OK;
 }
 
-// builds (captures) the graph of one tick for this slot, callback length and format.
-// Captured on a stream of its own: the dispatcher thread may be waiting on an event of the
-// working stream at the same moment, which a capture in progress on that stream does not survive.
-static int bd_live_build_graph(bd_live *L, bd_live_slot &s, uint32_t n, int format, hipGraphExec_t *out)
-{
-    const size_t M = L->n_streams;
-    const size_t elem = format == BD_FMT_F32 ? 4 : 2;
-    hipGraph_t graph = nullptr;
-    // Zero-copy tick (default): the kernels read the pinned staging buffer and write the pinned result
-    // buffer through their device addresses, so a tick is one kernel node (two with a format
-    // conversion) instead of copy + kernel + copy.  BD_LIVE_ZERO_COPY=0 keeps the copies.
-    const void *raw = s.d_raw;
-    bd_live_result *res = s.d_res;
-    if (L->zero_copy) {
-        void *dp_in = nullptr, *dp_res = nullptr;
-        BD_HIP(hipHostGetDevicePointer(&dp_in, s.h_in, 0));
-        BD_HIP(hipHostGetDevicePointer(&dp_res, s.h_res, 0));
-        raw = dp_in; res = (bd_live_result *)dp_res;
-    }
-    BD_HIP(hipStreamBeginCapture(L->cap_stream, hipStreamCaptureModeRelaxed));
-    hipError_t e = hipSuccess;
-    if (!L->zero_copy) e = hipMemcpyAsync(s.d_raw, s.h_in, M * n * elem, hipMemcpyHostToDevice, L->cap_stream);
-    const int16_t *in16 = (const int16_t *)raw;
-    if (e == hipSuccess && format != BD_FMT_I16) {
-        const uint64_t total = (uint64_t)M * n;
-        hipLaunchKernelGGL(bd_live_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, L->cap_stream,
-                           raw, s.d_i16, total, format);
-        in16 = s.d_i16;
-    }
-    if (e == hipSuccess) {
-        bd_live_args a;
-        a.in = in16; a.in_stride = n; a.n = n;
-        a.ring = L->d_ring; a.state = L->d_state; a.result = res; a.plan = L->plan;
-        hipLaunchKernelGGL(bd_live_tick_kernel, dim3((unsigned)M), dim3(256), 0, L->cap_stream, a);
-        if (!L->zero_copy) e = hipMemcpyAsync(s.h_res, s.d_res, M * sizeof(bd_live_result), hipMemcpyDeviceToHost, L->cap_stream);
-    }
-    hipError_t e2 = hipStreamEndCapture(L->cap_stream, &graph);
-    if (e != hipSuccess || e2 != hipSuccess) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return bd_check_hip(e != hipSuccess ? e : e2, "capture live tick graph");
-    }
-    e = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    return bd_check_hip(e, "instantiate live tick graph");
-}
-
 extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int format, uint64_t *tick_id)
 {
     if (!L || !samples) { bd_set_error("bd_live_submit: null argument"); return BD_ERR_INVALID_ARG; }
     if (n == 0) { bd_set_error("empty window (the reference panics at window_stats.rs:51)"); return BD_ERR_EMPTY_WINDOW; }
     if (n > L->max_len) { bd_set_error("callback of %u samples exceeds max_callback_len %u", n, L->max_len); return BD_ERR_INVALID_ARG; }
     if (format != BD_FMT_I16 && format != BD_FMT_U16 && format != BD_FMT_F32) { bd_set_error("unknown sample format %d", format); return BD_ERR_INVALID_ARG; }
-    if (L->dispatch_error != BD_OK) { bd_set_error("live dispatcher failed"); return L->dispatch_error; }
     uint64_t tick;
     bd_live_slot *s;
     {
@@ -569,22 +603,17 @@ extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int f
             bd_set_error("live ring full: poll tick %llu first", (unsigned long long)s->tick);
             return BD_ERR_UNSUPPORTED;
         }
-        L->cv.wait(lk, [&] { return !s->busy; }); // the dispatcher frees slots
+        // the dispatcher frees slots; if it has failed nobody will
+        L->cv.wait(lk, [&] { return !s->busy || L->dispatch_error.load() != BD_OK; });
+        if (L->dispatch_error.load() != BD_OK) { bd_set_error("live dispatcher failed"); return L->dispatch_error.load(); }
     }
     int prev = 0;
     BD_HIP(hipGetDevice(&prev));
     if (prev != L->device) BD_HIP(hipSetDevice(L->device));
     const size_t elem = format == BD_FMT_F32 ? 4 : 2;
     memcpy(s->h_in, samples, (size_t)L->n_streams * n * elem);
-    int st = BD_OK;
-    auto key = std::make_tuple(n, format);
-    auto it = s->graphs.find(key);
-    if (it == s->graphs.end()) {
-        hipGraphExec_t g = nullptr;
-        st = bd_live_build_graph(L, *s, n, format, &g);
-        if (st == BD_OK) it = s->graphs.emplace(key, g).first;
-    }
-    if (st == BD_OK) st = bd_check_hip(hipGraphLaunch(it->second, L->stream), "launch live tick graph");
+    s->h_ctl->n = n;
+    int st = bd_check_hip(hipGraphLaunch(s->graph[format], L->stream), "launch live tick graph");
     if (st == BD_OK) st = bd_check_hip(hipEventRecord(s->done, L->stream), "record tick event");
     if (prev != L->device) (void)hipSetDevice(prev);
     if (st != BD_OK) return st;
@@ -613,8 +642,8 @@ extern "C" int bd_live_poll(bd_live *L, uint64_t tick_id, int wait, uint8_t *bea
         // results are delivered through the callback; poll only waits for the tick
         std::unique_lock<std::mutex> lk(L->mu);
         if (!wait) return L->next_free > tick_id ? 1 : 0;
-        L->cv.wait(lk, [&] { return L->next_free > tick_id || L->dispatch_error != BD_OK; });
-        return L->dispatch_error != BD_OK ? L->dispatch_error : 1;
+        L->cv.wait(lk, [&] { return L->next_free > tick_id || L->dispatch_error.load() != BD_OK; });
+        return L->dispatch_error.load() != BD_OK ? L->dispatch_error.load() : 1;
     }
     if (wait) BD_HIP(hipEventSynchronize(s->done));
     else {

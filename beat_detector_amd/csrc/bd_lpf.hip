@@ -230,33 +230,16 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     bd_lpf_finish(a, s, j0, (unsigned)rows, lane, xmax, ymax);
 }
 
-__global__ void bd_fill_zero_kernel(float *values, uint8_t *flags, uint64_t n_cb, uint64_t out_stride, uint64_t n)
-{
-    const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint64_t o = (i / n_cb) * out_stride + i % n_cb;
-        if (values) values[o] = 0.f;
-        flags[o] = 0;
-    }
-}
-
 int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                   uint64_t n_samples, uint64_t stride, uint32_t callback_len,
                   float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st)
 {
     const uint64_t n_cb = n_samples / callback_len;
     if (n_cb == 0 || n_streams == 0) return BD_OK;
-    if (!plan.alpha_valid) {
-        // alpha is NaN (sampling rate wraps to 0 as u16, lpf.rs:69): every
-        // filtered sample becomes 0 and no window can reach its threshold
-        const uint64_t n = n_streams * n_cb;
-        const uint64_t grid64 = (n + 255) / 256;
-        dim3 grid_dims;
-    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-        hipLaunchKernelGGL(bd_fill_zero_kernel, grid_dims, dim3(256), 0, st, values, flags, n_cb, out_stride, n);
-        bd_set_last_kernel("bd_fill_zero_kernel");
-        return bd_check_hip(hipGetLastError(), "launch bd_fill_zero_kernel");
-    }
+    // A NaN alpha (the sampling rate wraps to 0 as u16, lpf.rs:69) needs no path of its own: the
+    // reference turns every filtered sample into 0 (`NaN as i16`) and compares 0 with the window's
+    // threshold; in the kernel y becomes NaN, the running maximum (which skips NaNs) stays 0, and the
+    // same comparison follows.
     bd_lpf_args a;
     a.samples = samples; a.values = values; a.flags = flags;
     a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;

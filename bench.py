@@ -437,6 +437,7 @@ def run_chunked_onset(ctx, steps, warmup, tracks=0, seconds=0, chunk=0):
 # live path: 256 concurrent streams, one tick = one 1024-sample callback per stream
 # --------------------------------------------------------------------------------------------
 def run_live(ctx, ticks=400, streams=256, L=1024):
+    import gc
     import numpy as np
     bd = ctx.bd
     out = {"workload": "live_256", "streams": streams, "callback_len": L, "ticks": ticks,
@@ -444,17 +445,28 @@ def run_live(ctx, ticks=400, streams=256, L=1024):
            "measured": "submit -> result on the host, per tick (pinned ring, one HIP graph replay per tick)"}
     x = bd.synth_fill_host(streams, L * 64, seed=11)
     wins = [np.ascontiguousarray(x[:, i * L:(i + 1) * L]) for i in range(64)]
+    # the same with callbacks of 500-540 samples, a new length on most ticks (what the reference's
+    # author reports for Linux, spectrum.rs:40-42)
+    rng = np.random.default_rng(1)
+    var_len = rng.integers(500, 541, ticks)
     for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
-        live = bd.Live(kind, SR, streams, max_callback_len=L, depth=4)
-        lat = []
-        for t in range(ticks):                     # every tick counts: the first ones included
-            t0 = time.perf_counter()
-            tick = live.submit(wins[t % 64])
-            live.poll(tick)
-            lat.append((time.perf_counter() - t0) * 1e6)
-        live.close()
-        lat = np.array(lat)
-        out[kind.name] = {"p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)),
+        for label, lengths in ((kind.name, None), (kind.name + "_500_540", var_len)):
+            live = bd.Live(kind, SR, streams, max_callback_len=L, depth=4)
+            blocks = wins if lengths is None else [np.ascontiguousarray(x[:, 100 * (t % 8):100 * (t % 8) + int(n)])
+                                                   for t, n in enumerate(lengths)]
+            lat = []
+            gc.collect()
+            gc.disable()   # a collection of the interpreter's heap inside a tick is not the path's latency
+            for t in range(ticks):                     # every tick counts: the first ones included
+                blk = blocks[t % len(blocks)]
+                t0 = time.perf_counter()
+                tick = live.submit(blk)
+                live.poll(tick)
+                lat.append((time.perf_counter() - t0) * 1e6)
+            gc.enable()
+            live.close()
+            lat = np.array(lat)
+            out[label] = {"p50_us": float(np.percentile(lat, 50)), "p99_us": float(np.percentile(lat, 99)),
                           "max_us": float(lat.max()), "first_tick_us": float(lat[0])}
     return out
 

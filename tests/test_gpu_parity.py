@@ -277,6 +277,12 @@ def test_lpf_edge_signals_and_params(bd, oracle):
     for c in (dict(), dict(lpf_cutoff_hz=4000), dict(lpf_ratio=0.2), dict(lpf_ratio=1.5), dict(lpf_cutoff_hz=0),
               dict(min_amplitude=0, lpf_ratio=0.0)):
         _compare(bd, oracle, "LPF", SR, x, 1024, bd.Params.default(**c), oracle.default_params(**c), exact_values=True)
+    # sampling rate 65536 is 0 `as u16` (lpf.rs:69): alpha is NaN, every filtered sample becomes 0, and a window
+    # still fires whenever its threshold is <= 0 (a silent window without an amplitude gate, or ratio <= 0)
+    for c in (dict(), dict(min_amplitude=0, lpf_ratio=0.0), dict(min_amplitude=0), dict(lpf_ratio=-0.5)):
+        for L in (1024, 441):
+            _compare(bd, oracle, "LPF", 65536, x, L, bd.Params.default(**c), oracle.default_params(**c),
+                     exact_values=True)
 
 
 def test_refractory_rule_dense_decisions(bd, oracle):

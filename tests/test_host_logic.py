@@ -97,3 +97,20 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".inc")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert not re.search(r"\boracle\b|bdo_|bd_oracle", text), os.path.join(dirpath, f)
+
+
+def test_multi_device_entry_validates_before_it_starts_workers(bd):
+    """Argument errors of bd_analyze_batch_multi come back once, before any pointer is offset per shard."""
+    import ctypes as C
+    L = bd.lib()
+    dev = (C.c_int * 2)(0, 0)
+    x = (C.c_int16 * 4096)()
+    cnt = (C.c_uint32 * 2)()
+    vp = lambda a: C.cast(a, C.c_void_p)
+    assert L.bd_analyze_batch_multi(1, 44100, None, None, 2, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, dev, 2) == -1
+    assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 2, 2048, 2048, 512, None, None, None, None, None, 0, dev, 2) == -1
+    assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 2, 2048, 1024, 512, None, None, vp(cnt), None, None, 0, dev, 2) == -1
+    assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 2, 2048, 2048, 0, None, None, vp(cnt), None, None, 0, dev, 2) == -5
+    assert L.bd_analyze_batch_multi(7, 44100, None, vp(x), 2, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, dev, 2) == -1
+    assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 2, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, None, 0) == -1
+    assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 0, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, dev, 2) == 0
