@@ -1,185 +1,385 @@
-//! Raw bindings and thin safe wrappers for `libbeatdet_hip.so`
-//! (`include/beat_detector_hip.h`): the GPU implementation of beat-detector's
-//! per-window analysis path.  SOURCE ONLY, not compiled in this repository's
-//! build environment.
+//! GPU (MI355X / gfx950) implementation of beat-detector's per-window analysis
+//! path behind the crate's own public interface: [`BeatInfo`], [`Strategy`],
+//! [`StrategyKind`] and [`record::start_listening`] have the shapes of the
+//! parent crate (`src/lib.rs:51-185`, `src/record.rs:39-44`), so a caller written
+//! against it compiles against this crate by changing the `use` line.  All
+//! arithmetic happens in `libbeatdet_hip.so` (`include/beat_detector_hip.h`),
+//! declared in [`ffi`]; there is no CPU implementation here.
 //!
-//! The parent crate keeps its `Strategy` trait, `StrategyKind` enum and
-//! `record::start_listening` signature; `StrategyKind::detector` returns a
-//! type that wraps [`Detector`].
-#![allow(non_camel_case_types)]
+//! SOURCE ONLY: the environment this repository is built in has no Rust
+//! toolchain, so the crate has not been compiled.  `tests/test_cabi_symbols.py`
+//! keeps every declaration of [`ffi`] equal, argument by argument, to the header.
+//!
+//! Two ways to wire it into the parent crate:
+//! * replace the bodies of `StrategyKind::detector/name/description` by the ones
+//!   below (three lines each) and leave `record.rs` untouched: it only calls
+//!   `strategy.detector(rate)` and `detector.is_beat(&[i16])`
+//!   (`src/record.rs:85,95,109,123`);
+//! * or depend on this crate and re-export `BeatInfo`, `Strategy`, `StrategyKind`.
+pub mod ffi;
+pub mod record;
 
 use std::ffi::CStr;
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::c_int;
 
-pub const BD_OK: c_int = 0;
-pub const BD_KIND_LPF: c_int = 0;
-pub const BD_KIND_SPECTRUM: c_int = 1;
-
-#[repr(C)]
-#[derive(Debug, Clone, Copy)]
-pub struct bd_params {
-    pub min_amplitude: u32,
-    pub min_beat_gap_ms: u32,
-    pub spectrum_max_hz: f32,
-    pub spectrum_threshold: f32,
-    pub spectrum_divisor: u32,
-    pub spectrum_include_dc: u32,
-    pub spectrum_inclusive: u32,
-    pub spectrum_dc_packs_nyquist: u32,
-    pub lpf_cutoff_hz: u32,
-    pub lpf_ratio: f32,
-}
-
-#[repr(C)]
-pub struct bd_detector {
-    _private: [u8; 0],
-}
-
-extern "C" {
-    pub fn bd_default_params(p: *mut bd_params);
-    pub fn bd_last_error() -> *const c_char;
-    pub fn bd_strerror(status: c_int) -> *const c_char;
-    pub fn bd_device_count(count: *mut c_int) -> c_int;
-    pub fn bd_kind_count() -> c_int;
-    pub fn bd_kind_name(kind: c_int) -> *const c_char;
-    pub fn bd_kind_description(kind: c_int) -> *const c_char;
-    pub fn bd_kind_min_duration_between_beats_ms(kind: c_int) -> u32;
-    pub fn bd_detector_create(
-        kind: c_int,
-        sampling_rate: u32,
-        params: *const bd_params,
-        device: c_int,
-        out: *mut *mut bd_detector,
-    ) -> c_int;
-    pub fn bd_detector_is_beat(d: *mut bd_detector, samples: *const i16, n: usize, relative_ms: *mut u32) -> c_int;
-    pub fn bd_detector_kind(d: *const bd_detector) -> c_int;
-    pub fn bd_detector_destroy(d: *mut bd_detector);
-    pub fn bd_batch_callbacks(n_samples: u64, callback_len: u32) -> u64;
-    pub fn bd_batch_max_beats(kind: u32, sampling_rate: u32, params: *const bd_params, n_samples: u64, callback_len: u32) -> u32;
-    pub fn bd_analyze_batch(
-        kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64,
-        n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8, out_stride: u64,
-        beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, hip_stream: *mut c_void,
-    ) -> c_int;
-    pub fn bd_analyze_batch_host(
-        kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64,
-        n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8,
-        beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, device: c_int,
-    ) -> c_int;
-    pub fn bd_refractory(
-        sampling_rate: u32, params: *const bd_params, callback_len: u32, flags: *const u8, flags_stride: u64,
-        n_streams: u64, n_callbacks: u64, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32,
-        max_beats: u32, hip_stream: *mut c_void,
-    ) -> c_int;
-    // Extension analyses: no counterpart in the parent crate (device pointers, enqueue only).
-    pub fn bd_onset_default_params(p: *mut bd_onset_params);
-    pub fn bd_onset_frames(n_samples: u64, fft_len: u32, hop: u32) -> u64;
-    pub fn bd_onset_batch(
-        sampling_rate: u32, p: *const bd_onset_params, samples: *const i16, n_streams: u64, n_samples: u64,
-        stream_stride: u64, flux: *mut f32, band_energy: *mut f32, out_stride: u64, onset_count: *mut u32,
-        onset_frame: *mut u32, onset_ms: *mut u32, max_onsets: u32, hip_stream: *mut c_void,
-    ) -> c_int;
-    pub fn bd_biquad_default_params(p: *mut bd_biquad_params);
-    pub fn bd_biquad_envelope(
-        sampling_rate: u32, params: *const bd_biquad_params, design: *const c_void, samples: *const i16,
-        n_streams: u64, n_samples: u64, stream_stride: u64, values: *mut f32, flags: *mut u8, out_stride: u64,
-        hip_stream: *mut c_void,
-    ) -> c_int;
-}
-
-/// `bd_onset_params` of the C header.
-#[repr(C)]
-#[derive(Clone, Copy, Debug)]
-pub struct bd_onset_params {
-    pub fft_len: u32,
-    pub hop: u32,
-    pub window: u32,
-    pub band_max_hz: f32,
-    pub mean_frames: u32,
-    pub max_frames: u32,
-    pub delta: f32,
-    pub lambda: f32,
-    pub min_gap_ms: u32,
-    pub use_median: u32,
-}
-
-/// `bd_biquad_params` of the C header.
-#[repr(C)]
-#[derive(Clone, Copy, Debug)]
-pub struct bd_biquad_params {
-    pub cutoff_hz: u32,
-    pub q_factor: f32,
-    pub window_len: u32,
-    pub ratio: f32,
-    pub min_amplitude: u32,
-}
-
-/// Message of the last failed call on this thread.
+/// Message of the last failed call on this thread (`bd_last_error`).
 pub fn last_error() -> String {
-    unsafe { CStr::from_ptr(bd_last_error()).to_string_lossy().into_owned() }
+    unsafe { CStr::from_ptr(ffi::bd_last_error()).to_string_lossy().into_owned() }
 }
 
-/// Owning handle of one GPU detector (`StrategyKind::detector`).
+fn static_str(p: *const std::os::raw::c_char) -> &'static str {
+    // bd_kind_name / bd_kind_description return string literals of the library
+    if p.is_null() {
+        return "";
+    }
+    unsafe { CStr::from_ptr(p) }.to_str().unwrap_or("")
+}
+
+/// Information about a detected beat (`src/lib.rs:51-66`).
 #[derive(Debug)]
-pub struct Detector {
-    raw: *mut bd_detector,
+pub struct BeatInfo {
+    relative_ms: u32,
 }
 
-// The reference's detectors are `Send` but not `Sync` (src/lib.rs:155); same here.
-unsafe impl Send for Detector {}
+impl BeatInfo {
+    #[inline(always)]
+    pub const fn new(relative_ms: u32) -> Self {
+        Self { relative_ms }
+    }
 
-impl Detector {
-    pub fn new(kind: c_int, sampling_rate: u32) -> Result<Self, String> {
+    #[inline(always)]
+    pub const fn relative_ms(&self) -> u32 {
+        self.relative_ms
+    }
+}
+
+/// The per-window strategy interface (`src/lib.rs:72-137`).  The two shared
+/// gates of the parent trait (`last_beat_beyond_threshold`,
+/// `amplitude_high_enough`) take the parent's private `AnalysisState` /
+/// `WindowStats`; on the GPU they are part of the kernel, so they are not
+/// repeated here.
+pub trait Strategy {
+    /// `Some(BeatInfo)` if the callback's samples complete a beat.
+    fn is_beat(&self, samples: &[i16]) -> Option<BeatInfo>;
+
+    /// The [`StrategyKind`] of this detector.
+    fn kind(&self) -> StrategyKind;
+
+    fn name() -> &'static str
+    where
+        Self: Sized;
+
+    fn description() -> &'static str
+    where
+        Self: Sized;
+
+    fn min_duration_between_beats_ms() -> u32
+    where
+        Self: Sized;
+}
+
+/// `src/lib.rs:142-185`; discriminants follow `values()` and the C header.
+#[derive(Debug, PartialEq, Eq, Hash, Clone, Copy)]
+#[non_exhaustive]
+pub enum StrategyKind {
+    LPF,
+    Spectrum,
+}
+
+impl StrategyKind {
+    /// The `kind` integer of the C ABI (`BD_KIND_*`).
+    #[inline(always)]
+    pub const fn as_raw(&self) -> c_int {
+        match self {
+            StrategyKind::LPF => ffi::BD_KIND_LPF,
+            StrategyKind::Spectrum => ffi::BD_KIND_SPECTRUM,
+        }
+    }
+
+    /// A detector whose state and arithmetic live on the GPU
+    /// (`StrategyKind::detector`, `src/lib.rs:155-161`).  Panics if the library
+    /// cannot create it (no GPU): the parent's constructors cannot fail, and its
+    /// set-up errors are panics as well (`src/record.rs:56,135,138`).
+    #[inline(always)]
+    pub fn detector(&self, sampling_rate: u32) -> Box<dyn Strategy + Send> {
+        match self {
+            StrategyKind::LPF => Box::new(HipLpfDetector(HipDetector::new(*self, sampling_rate))),
+            StrategyKind::Spectrum => Box::new(HipSpectrumDetector(HipDetector::new(*self, sampling_rate))),
+        }
+    }
+
+    pub fn name(&self) -> &'static str {
+        static_str(unsafe { ffi::bd_kind_name(self.as_raw()) })
+    }
+
+    pub fn description(&self) -> &'static str {
+        static_str(unsafe { ffi::bd_kind_description(self.as_raw()) })
+    }
+
+    pub fn values() -> Vec<Self> {
+        vec![Self::LPF, Self::Spectrum]
+    }
+}
+
+/// Owner of one `bd_detector` handle.
+#[derive(Debug)]
+pub struct HipDetector {
+    raw: *mut ffi::bd_detector,
+    kind: StrategyKind,
+}
+
+// The parent's detectors are `Send` but not `Sync` (`Box<dyn Strategy + Send>`, src/lib.rs:155);
+// a handle is used by one thread at a time.
+unsafe impl Send for HipDetector {}
+
+impl HipDetector {
+    pub fn try_new(kind: StrategyKind, sampling_rate: u32) -> Result<Self, String> {
         let mut raw = std::ptr::null_mut();
-        let rc = unsafe { bd_detector_create(kind, sampling_rate, std::ptr::null(), -1, &mut raw) };
-        if rc == BD_OK {
-            Ok(Self { raw })
+        let rc = unsafe { ffi::bd_detector_create(kind.as_raw(), sampling_rate, std::ptr::null(), -1, &mut raw) };
+        if rc == ffi::BD_OK {
+            Ok(Self { raw, kind })
         } else {
             Err(last_error())
         }
     }
 
-    /// `Strategy::is_beat`: `Some(relative_ms)` on a beat.
-    pub fn is_beat(&self, samples: &[i16]) -> Result<Option<u32>, String> {
-        let mut ms = 0u32;
-        match unsafe { bd_detector_is_beat(self.raw, samples.as_ptr(), samples.len(), &mut ms) } {
-            1 => Ok(Some(ms)),
-            0 => Ok(None),
-            _ => Err(last_error()),
+    pub fn new(kind: StrategyKind, sampling_rate: u32) -> Self {
+        match Self::try_new(kind, sampling_rate) {
+            Ok(d) => d,
+            Err(e) => panic!("bd_detector_create: {}", e),
         }
     }
-}
 
-impl Drop for Detector {
-    fn drop(&mut self) {
-        unsafe { bd_detector_destroy(self.raw) }
+    /// `Strategy::is_beat`.  An empty slice panics like the parent (`window_stats.rs:51`).
+    pub fn is_beat(&self, samples: &[i16]) -> Option<BeatInfo> {
+        let mut ms = 0u32;
+        match unsafe { ffi::bd_detector_is_beat(self.raw, samples.as_ptr(), samples.len(), &mut ms) } {
+            1 => Some(BeatInfo::new(ms)),
+            0 => None,
+            e => panic!("bd_detector_is_beat: status {} ({})", e, last_error()),
+        }
+    }
+
+    pub fn kind(&self) -> StrategyKind {
+        self.kind
+    }
+
+    /// (analysed value, decision before the refractory rule) of the last call.
+    pub fn last(&self) -> (f32, bool) {
+        let (mut v, mut c) = (0f32, 0 as c_int);
+        unsafe { ffi::bd_detector_last(self.raw, &mut v, &mut c) };
+        (v, c != 0)
     }
 }
 
-/// Beats of many equally long streams (stream-major `samples`, `n_samples` each)
-/// analysed in one batch on the current GPU: per stream, `(callback index, relative_ms)`.
-pub fn analyze_batch(kind: c_int, sampling_rate: u32, samples: &[i16], n_samples: usize, callback_len: u32)
-    -> Result<Vec<Vec<(u32, u32)>>, String> {
-    assert!(n_samples > 0 && samples.len() % n_samples == 0);
+impl Drop for HipDetector {
+    fn drop(&mut self) {
+        unsafe { ffi::bd_detector_destroy(self.raw) }
+    }
+}
+
+/// Replacement of `LpfBeatDetector` (`src/strategies/lpf.rs:34-115`).
+#[derive(Debug)]
+pub struct HipLpfDetector(HipDetector);
+
+/// Replacement of `SABeatDetector` (`src/strategies/spectrum.rs:37-132`).
+#[derive(Debug)]
+pub struct HipSpectrumDetector(HipDetector);
+
+impl HipLpfDetector {
+    pub fn new(sampling_rate: u32) -> Self {
+        Self(HipDetector::new(StrategyKind::LPF, sampling_rate))
+    }
+}
+
+impl HipSpectrumDetector {
+    pub fn new(sampling_rate: u32) -> Self {
+        Self(HipDetector::new(StrategyKind::Spectrum, sampling_rate))
+    }
+}
+
+impl Strategy for HipLpfDetector {
+    #[inline(always)]
+    fn is_beat(&self, samples: &[i16]) -> Option<BeatInfo> {
+        self.0.is_beat(samples)
+    }
+
+    fn kind(&self) -> StrategyKind {
+        StrategyKind::LPF
+    }
+
+    fn name() -> &'static str {
+        StrategyKind::LPF.name()
+    }
+
+    fn description() -> &'static str {
+        StrategyKind::LPF.description()
+    }
+
+    fn min_duration_between_beats_ms() -> u32 {
+        unsafe { ffi::bd_kind_min_duration_between_beats_ms(ffi::BD_KIND_LPF) }
+    }
+}
+
+impl Strategy for HipSpectrumDetector {
+    #[inline(always)]
+    fn is_beat(&self, samples: &[i16]) -> Option<BeatInfo> {
+        self.0.is_beat(samples)
+    }
+
+    fn kind(&self) -> StrategyKind {
+        StrategyKind::Spectrum
+    }
+
+    fn name() -> &'static str {
+        StrategyKind::Spectrum.name()
+    }
+
+    fn description() -> &'static str {
+        StrategyKind::Spectrum.description()
+    }
+
+    fn min_duration_between_beats_ms() -> u32 {
+        unsafe { ffi::bd_kind_min_duration_between_beats_ms(ffi::BD_KIND_SPECTRUM) }
+    }
+}
+
+/// Result of a batched analysis: per stream, `(callback index, BeatInfo)`.
+pub type BeatLists = Vec<Vec<(u32, BeatInfo)>>;
+
+fn beat_lists(count: &[u32], idx: &[u32], ms: &[u32], max_beats: usize) -> BeatLists {
+    count
+        .iter()
+        .enumerate()
+        .map(|(s, &c)| {
+            let n = (c as usize).min(max_beats);
+            (0..n).map(|i| (idx[s * max_beats + i], BeatInfo::new(ms[s * max_beats + i]))).collect()
+        })
+        .collect()
+}
+
+/// The new batched entry point: many equally long streams (stream-major
+/// `samples`, `n_samples` each) through one strategy on the current GPU; for
+/// every stream the result of the loop `for window in chunks(callback_len) {
+/// detector.is_beat(window) }` of the parent's harness (`src/lib.rs:276-292`).
+pub fn analyze_batch(kind: StrategyKind, sampling_rate: u32, samples: &[i16], n_samples: usize, callback_len: u32) -> Result<BeatLists, String> {
+    if n_samples == 0 || samples.len() % n_samples != 0 {
+        return Err("samples.len() must be a multiple of n_samples".to_string());
+    }
     let n_streams = samples.len() / n_samples;
-    let max_beats = unsafe { bd_batch_max_beats(kind as u32, sampling_rate, std::ptr::null(), n_samples as u64, callback_len) }.max(1);
+    let max_beats =
+        unsafe { ffi::bd_batch_max_beats(kind.as_raw() as u32, sampling_rate, std::ptr::null(), n_samples as u64, callback_len) }.max(1);
     let mut count = vec![0u32; n_streams];
     let mut idx = vec![0u32; n_streams * max_beats as usize];
     let mut ms = vec![0u32; n_streams * max_beats as usize];
     let rc = unsafe {
-        bd_analyze_batch_host(
-            kind, sampling_rate, std::ptr::null(), samples.as_ptr(), n_streams as u64, n_samples as u64,
-            n_samples as u64, callback_len, std::ptr::null_mut(), std::ptr::null_mut(), count.as_mut_ptr(),
-            idx.as_mut_ptr(), ms.as_mut_ptr(), max_beats, -1,
+        ffi::bd_analyze_batch_host(
+            kind.as_raw(),
+            sampling_rate,
+            std::ptr::null(),
+            samples.as_ptr(),
+            n_streams as u64,
+            n_samples as u64,
+            n_samples as u64,
+            callback_len,
+            std::ptr::null_mut(),
+            std::ptr::null_mut(),
+            count.as_mut_ptr(),
+            idx.as_mut_ptr(),
+            ms.as_mut_ptr(),
+            max_beats,
+            -1,
         )
     };
-    if rc != BD_OK {
+    if rc != ffi::BD_OK {
         return Err(last_error());
     }
-    Ok((0..n_streams)
-        .map(|s| {
-            let n = (count[s] as usize).min(max_beats as usize);
-            (0..n).map(|i| (idx[s * max_beats as usize + i], ms[s * max_beats as usize + i])).collect()
-        })
-        .collect())
+    Ok(beat_lists(&count, &idx, &ms, max_beats as usize))
+}
+
+/// The same, sharded by stream over several GPUs of the node (contiguous
+/// shards, no traffic between GPUs).
+pub fn analyze_batch_multi(kind: StrategyKind, sampling_rate: u32, samples: &[i16], n_samples: usize, callback_len: u32, devices: &[i32]) -> Result<BeatLists, String> {
+    if n_samples == 0 || samples.len() % n_samples != 0 {
+        return Err("samples.len() must be a multiple of n_samples".to_string());
+    }
+    let n_streams = samples.len() / n_samples;
+    let max_beats =
+        unsafe { ffi::bd_batch_max_beats(kind.as_raw() as u32, sampling_rate, std::ptr::null(), n_samples as u64, callback_len) }.max(1);
+    let mut count = vec![0u32; n_streams];
+    let mut idx = vec![0u32; n_streams * max_beats as usize];
+    let mut ms = vec![0u32; n_streams * max_beats as usize];
+    let devs: Vec<c_int> = devices.iter().map(|&d| d as c_int).collect();
+    let rc = unsafe {
+        ffi::bd_analyze_batch_multi(
+            kind.as_raw(),
+            sampling_rate,
+            std::ptr::null(),
+            samples.as_ptr(),
+            n_streams as u64,
+            n_samples as u64,
+            n_samples as u64,
+            callback_len,
+            std::ptr::null_mut(),
+            std::ptr::null_mut(),
+            count.as_mut_ptr(),
+            idx.as_mut_ptr(),
+            ms.as_mut_ptr(),
+            max_beats,
+            devs.as_ptr(),
+            devs.len() as c_int,
+        )
+    };
+    if rc != ffi::BD_OK {
+        return Err(last_error());
+    }
+    Ok(beat_lists(&count, &idx, &ms, max_beats as usize))
+}
+
+/// Many concurrent input streams advanced together, one callback per stream and
+/// tick (`bd_live_*`): the multi-stream form of the loop in `src/record.rs:87-146`.
+#[derive(Debug)]
+pub struct Live {
+    raw: *mut ffi::bd_live,
+    n_streams: usize,
+}
+
+unsafe impl Send for Live {}
+
+impl Live {
+    pub fn new(kind: StrategyKind, sampling_rate: u32, n_streams: u32, max_callback_len: u32) -> Result<Self, String> {
+        let mut raw = std::ptr::null_mut();
+        let rc = unsafe { ffi::bd_live_create(kind.as_raw(), sampling_rate, std::ptr::null(), n_streams, max_callback_len, 0, -1, &mut raw) };
+        if rc == ffi::BD_OK {
+            Ok(Self { raw, n_streams: n_streams as usize })
+        } else {
+            Err(last_error())
+        }
+    }
+
+    /// One tick of `i16` samples, `[n_streams][n]`; returns the beat of every stream.
+    pub fn tick(&mut self, samples: &[i16]) -> Result<Vec<Option<BeatInfo>>, String> {
+        if self.n_streams == 0 || samples.len() % self.n_streams != 0 {
+            return Err("samples.len() must be a multiple of the number of streams".to_string());
+        }
+        let n = (samples.len() / self.n_streams) as u32;
+        let mut tick = 0u64;
+        let rc = unsafe { ffi::bd_live_submit(self.raw, samples.as_ptr() as *const _, n, ffi::BD_FMT_I16, &mut tick) };
+        if rc != ffi::BD_OK {
+            return Err(last_error());
+        }
+        let mut beats = vec![0u8; self.n_streams];
+        let mut ms = vec![0u32; self.n_streams];
+        let rc = unsafe { ffi::bd_live_poll(self.raw, tick, 1, beats.as_mut_ptr(), ms.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc < 0 {
+            return Err(last_error());
+        }
+        Ok(beats.iter().zip(ms.iter()).map(|(&b, &m)| if b != 0 { Some(BeatInfo::new(m)) } else { None }).collect())
+    }
+}
+
+impl Drop for Live {
+    fn drop(&mut self) {
+        unsafe { ffi::bd_live_destroy(self.raw) }
+    }
 }
