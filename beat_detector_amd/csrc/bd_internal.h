@@ -49,6 +49,10 @@ int bd_spectrum_granule_max_bins(uint32_t gran);
 int bd_launch_spectrum_granule(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                                uint64_t n_samples, uint64_t stride, uint32_t callback_len,
                                float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);
+bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len);
+int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_cb_eval,
+                             uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
+                             uint64_t out_stride, hipStream_t st);
 int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                   uint64_t n_samples, uint64_t stride, uint32_t callback_len,
                   float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st);

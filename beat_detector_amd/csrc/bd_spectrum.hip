@@ -70,22 +70,20 @@ __device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int
     for (int c = 0; c < 4; c++) d[c] = bd_load_stream16(p + 16 * c);
 }
 
-#define BD_SPEC_MAX_RUN 512 // half-blocks per task, upper bound (LDS flag staging)
+#define BD_SPEC_MAX_RUN 128 // half-blocks per task, upper bound (LDS slots of a run)
 
-// per-wavefront state that lives across iterations
-struct bd_spec_carry {
-    // sums of the last half-block of the previous iteration (wave-uniform)
-    float re1, im1, re2, im2, amax;
+// Sums of one half-block, parked in LDS until the end of the run.
+struct __attribute__((aligned(16))) bd_spec_slot {
+    float re1, im1, re2, im2;
     int   dc, ny;
-    float   *lds_v;   // [BD_SPEC_MAX_RUN] values of the whole run
-    uint8_t *lds_f;   // [BD_SPEC_MAX_RUN] decisions of the whole run
+    float amax, pad;
 };
 
-// One iteration: four half-blocks (one per row of 16 lanes) held in `d`.
-template <int MODE, int NK, bool NYQ>
-__device__ __forceinline__ void bd_spec_iter(const bd_spec_args &a, const uint4 (&d)[4], int it, int64_t hb,
-                                             int64_t n_hb, uint64_t s, int g, int l,
-                                             float lc1, float ls1, float lc2, float ls2, bd_spec_carry &k)
+// One iteration: four half-blocks (one per row of 16 lanes) held in `d`; the row's sums go to
+// LDS slot `slot` (a negative slot belongs to a stand-in row and is dropped).
+template <int NK, bool NYQ>
+__device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int l,
+                                             float lc1, float ls1, float lc2, float ls2, bd_spec_slot *slots)
 {
     float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
     int dc = 0, ny = 0;
@@ -112,61 +110,55 @@ __device__ __forceinline__ void bd_spec_iter(const bd_spec_args &a, const uint4 
         }
     }
     // (a - i b) * (cos - i sin): apply the per-lane offset 8 l, then reduce the row
-    float re1 = 0.f, im1 = 0.f, re2 = 0.f, im2 = 0.f;
+    bd_spec_slot r;
+    r.re1 = r.im1 = r.re2 = r.im2 = 0.f;
     if (NK >= 1) {
-        re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
-        im1 = bd_row_sum(a1 * ls1 + b1 * lc1);
+        r.re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
+        r.im1 = bd_row_sum(a1 * ls1 + b1 * lc1);
     }
     if (NK >= 2) {
-        re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
-        im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
+        r.re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
+        r.im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
     }
-    dc = bd_row_sum(dc);
-    if (NYQ) ny = bd_row_sum(ny);
-    amax = bd_row_max(amax);
+    r.dc = bd_row_sum(dc);
+    r.ny = NYQ ? bd_row_sum(ny) : 0;
+    r.amax = bd_row_max(amax);
+    r.pad = 0.f;
+    // Lane 0 of each row parks the row's sums.  Combining neighbouring half-blocks into
+    // callbacks, magnitudes, scaling and the decision happen once per run with all lanes busy
+    // (bd_spec_finish) instead of on four lanes in every iteration.
+    if (l == 0 && slot >= 0) slots[slot] = r;
+}
 
-    // sums of the half-block just before this row's
-    const float p_re1 = bd_prev_row(re1, k.re1), p_im1 = bd_prev_row(im1, k.im1);
-    const float p_re2 = bd_prev_row(re2, k.re2), p_im2 = bd_prev_row(im2, k.im2);
-    const float p_amax = bd_prev_row(amax, k.amax);
-    const int p_dc = bd_prev_row(dc, k.dc);
-    const int p_ny = NYQ ? bd_prev_row(ny, k.ny) : 0;
-    if (MODE == 0) { // only the hop-512 ring reaches back into the previous iteration
-        k.re1 = bd_lane63(re1); k.im1 = bd_lane63(im1);
-        k.re2 = bd_lane63(re2); k.im2 = bd_lane63(im2);
-        k.dc = bd_lane63(dc);
-        if (NYQ) k.ny = bd_lane63(ny);
+// Callback i of the run from the sums of its two half-blocks: X_k = P_k(prev) + (-1)^k P_k(cur).
+template <int MODE, int NK, bool NYQ>
+__device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_spec_slot *slots, unsigned i,
+                                               float *value_out, uint8_t *flag_out)
+{
+    const bd_spec_slot p = slots[MODE == 0 ? i : 2 * i];
+    const bd_spec_slot c = slots[MODE == 0 ? i + 1 : 2 * i + 1];
+    const float x_dc = (float)(p.dc + c.dc);
+    float m0 = fabsf(x_dc);
+    if (NYQ) {
+        const float x_ny = (float)(p.ny + c.ny);
+        m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
     }
-
-    // Lane 0 of each row finishes the row's callback and parks the result in
-    // LDS; the results of the whole run are stored at its end by consecutive
-    // lanes (contiguous, full cache lines when the output rows are 128-byte
-    // aligned) instead of 4-byte and 1-byte stores from four lanes per iteration.
-    if (l == 0 && it >= 0 && (MODE == 0 || (g & 1))) {
-        // X_k = P_k(prev) + (-1)^k P_k(cur)
-        const float x_dc = (float)(p_dc + dc);
-        float m0 = fabsf(x_dc);
-        if (NYQ) {
-            const float x_ny = (float)(p_ny + ny);
-            m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
-        }
-        float best = a.include_dc ? m0 : 0.f;
-        if (NK >= 1) {
-            const float xr = p_re1 - re1, xi = p_im1 - im1;
-            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
-        }
-        if (NK >= 2) {
-            const float xr = p_re2 + re2, xi = p_im2 + im2;
-            best = fmaxf(best, sqrtf(xr * xr + xi * xi));
-        }
-        const float value = (a.divisor == 0.f) ? best : best / a.divisor;
-        const float wmax = fminf(MODE == 0 ? amax : fmaxf(amax, p_amax), 32767.f);
-        const bool gate = wmax >= (float)a.min_amp;
-        const int r = MODE == 0 ? g : (g >> 1);
-        constexpr int RPI = MODE == 0 ? 4 : 2;
-        k.lds_v[RPI * it + r] = value;
-        k.lds_f[RPI * it + r] = (gate && (value > a.threshold)) ? 1 : 0;
+    float best = a.include_dc ? m0 : 0.f;
+    if (NK >= 1) {
+        const float xr = p.re1 - c.re1, xi = p.im1 - c.im1;
+        best = fmaxf(best, sqrtf(xr * xr + xi * xi));
     }
+    if (NK >= 2) {
+        const float xr = p.re2 + c.re2, xi = p.im2 + c.im2;
+        best = fmaxf(best, sqrtf(xr * xr + xi * xi));
+    }
+    const float value = (a.divisor == 0.f) ? best : best / a.divisor;
+    // the amplitude gate looks at the callback's own samples (spectrum.rs:77): one half-block
+    // for 512-sample callbacks, both for 1024
+    const float wmax = fminf(MODE == 0 ? c.amax : fmaxf(c.amax, p.amax), 32767.f);
+    const bool gate = wmax >= (float)a.min_amp;
+    *value_out = value;
+    *flag_out = (gate && (value > a.threshold)) ? 1 : 0;
 }
 
 // MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
@@ -195,21 +187,23 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
     const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
 
-    bd_spec_carry k;
-    k.re1 = k.im1 = k.re2 = k.im2 = k.amax = 0.f;
-    k.dc = k.ny = 0;
-    __shared__ float lds_values[4][BD_SPEC_MAX_RUN];
-    __shared__ uint8_t lds_flags[4][BD_SPEC_MAX_RUN];
-    k.lds_v = lds_values[wave];
-    k.lds_f = lds_flags[wave];
+    // slot 0 of a hop-512 run is the half-block before the run; the others follow
+    __shared__ bd_spec_slot lds_slots[4][BD_SPEC_MAX_RUN + 4];
+    bd_spec_slot *slots = lds_slots[wave];
+    constexpr int SLOT0 = MODE == 0 ? 1 : 0;
+    if (MODE == 0 && hb0 == 0 && lane == 0) {
+        // before the stream the ring holds zeros (spectrum.rs:50-51)
+        bd_spec_slot z;
+        z.re1 = z.im1 = z.re2 = z.im2 = z.amax = z.pad = 0.f;
+        z.dc = z.ny = 0;
+        slots[0] = z;
+    }
 
     // Two register buffers, each filled one iteration ahead of its use.  Loads
     // are unconditional so that the compiler can count them (s_waitcnt vmcnt(4)
     // instead of vmcnt(0)): a half-block outside [hb_lo, n_hb) is replaced by
     // the nearest one inside (a line some lane of this wavefront reads anyway).
-    // Rows that loaded such a
-    // stand-in produce values that are never stored, and no stored value
-    // depends on them: a row's "previous half-block" is always a real one.
+    // Rows that loaded such a stand-in produce sums that no stored result uses.
     uint4 A[4], B[4];
     auto load = [&](uint4 (&d)[4], int it) {
         int64_t hb = hb0 + 4 * (int64_t)it + g;
@@ -218,7 +212,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         bd_load_hb(d, sp, hb, l);
     };
     auto run = [&](const uint4 (&d)[4], int it) {
-        bd_spec_iter<MODE, NK, NYQ>(a, d, it, hb0 + 4 * (int64_t)it + g, n_hb, s, g, l, lc1, ls1, lc2, ls2, k);
+        bd_spec_iter<NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
     };
     // Steady state: every load is issued one iteration ahead of its use.  The
     // last one or two iterations are peeled so that nothing is loaded twice.
@@ -237,7 +231,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     } else {
         run(A, it);
     }
-    // results of the run: consecutive lanes store consecutive callbacks
+    // results of the run: consecutive lanes finish and store consecutive callbacks
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint64_t cb0 = (uint64_t)(hb0 >> MODE);
@@ -246,10 +240,12 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const unsigned n_res = cb_left < n_res_run ? (unsigned)cb_left : n_res_run; // buffer stores past it are dropped
     const uint64_t o0 = s * a.out_stride + cb0;
     __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, n_res);
-    for (unsigned i = lane; i < n_res_run; i += 64) bd_store_stream_u8(rf, i, k.lds_f[i]);
-    if (a.values) {
-        __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values + o0, n_res * 4u);
-        for (unsigned i = lane; i < n_res_run; i += 64) bd_store_stream_f32(rv, i * 4u, k.lds_v[i]);
+    __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values ? a.values + o0 : nullptr, a.values ? n_res * 4u : 0u);
+    for (unsigned i = lane; i < n_res_run; i += 64) {
+        float value; uint8_t flag;
+        bd_spec_finish<MODE, NK, NYQ>(a, slots, i, &value, &flag);
+        bd_store_stream_u8(rf, i, flag);
+        bd_store_stream_f32(rv, i * 4u, value);   // a zero-sized descriptor drops the store
     }
 }
 
@@ -259,7 +255,8 @@ struct bd_spec_generic_args {
     float         *values;
     uint8_t       *flags;
     uint64_t       stride;
-    uint64_t       n_cb;
+    uint64_t       n_cb;     // callbacks per stream evaluated by this launch: j_first .. j_first + n_cb - 1
+    uint64_t       j_first;
     uint64_t       n_total;  // n_streams * n_cb
     uint64_t       out_stride;
     uint32_t       callback_len;
@@ -275,7 +272,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_generic_kernel(bd_spec_generi
     const int lane = threadIdx.x & 63;
     const uint64_t t = bd_block_index() * 4 + (threadIdx.x >> 6);
     if (t >= a.n_total) return;
-    const uint64_t s = t / a.n_cb, j = t - s * a.n_cb;
+    const uint64_t s = t / a.n_cb, j = a.j_first + (t - s * a.n_cb);
     const int16_t *sp = a.samples + s * a.stride;
     const int64_t end = (int64_t)(j + 1) * a.callback_len;
     // ring = samples [end-1024, end), zeros before the stream starts (spectrum.rs:50-51);
@@ -632,19 +629,30 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         const uint64_t j_min = (BD_RING_LEN + callback_len - 1) / callback_len - 1; // callbacks with (j + 1) L < 1024
         n_generic = j_min < n_cb ? j_min : n_cb;
     }
-    if (n_generic > 0) {
+    auto launch_generic = [&](uint64_t j_first, uint64_t count) -> int {
         bd_spec_generic_args a;
         a.samples = samples; a.values = values; a.flags = flags;
-        a.stride = stride; a.n_cb = n_generic; a.n_total = n_streams * n_generic; a.out_stride = out_stride;
+        a.stride = stride; a.n_cb = count; a.j_first = j_first; a.n_total = n_streams * count; a.out_stride = out_stride;
         a.callback_len = callback_len; a.min_amp = plan.min_amp;
         a.first_bin = plan.first_bin; a.last_bin = plan.last_bin;
         a.nyq = plan.dc_packs_nyquist; a.divisor = plan.divisor; a.threshold = plan.threshold;
         const uint64_t grid64 = (a.n_total + 3) / 4;
         dim3 grid_dims;
-    if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+        if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
         hipLaunchKernelGGL(bd_spectrum_generic_kernel, grid_dims, dim3(256), 0, st, a);
         bd_set_last_kernel("bd_spectrum_generic_kernel");
-        int rc = bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
+        return bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
+    };
+    // lengths around the reference's Linux callbacks (400 .. 640, off every grid): the split kernel, which
+    // multiplies every sample by its twiddles once; the last callback of a stream goes to the generic kernel
+    // (the split kernel's 16-byte loads may reach a few samples past a callback's end)
+    if (window_path && bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT")) {
+        int rc = launch_generic(n_cb - 1, 1);
+        if (rc != BD_OK || n_cb == 1) return rc;
+        return bd_launch_spectrum_split(plan, samples, n_streams, n_cb - 1, stride, callback_len, values, flags, out_stride, st);
+    }
+    if (n_generic > 0) {
+        int rc = launch_generic(0, n_generic);
         if (rc != BD_OK || n_generic == n_cb) return rc;
     }
     bd_win_args a;

@@ -1,0 +1,445 @@
+// Spectrum strategy, batched, for callback lengths of roughly 400 .. 640 samples that sit on no
+// grid (the reference's author reports "mostly 500-540" samples per callback on Linux,
+// src/strategies/spectrum.rs:40-42; 1024 elsewhere).
+//
+// The ring of callback j is the latest 1024 samples (spectrum.rs:65-68, :82-83).  With equal
+// callbacks of L samples, q = 1024 / L whole callbacks fit into it and t = 1024 - q L samples remain:
+//
+//     ring(j) = tail_t(callback j - q)  |  callback j - q + 1  |  ...  |  callback j
+//
+// so, with every partial sum anchored at the first sample of its piece,
+//
+//     X_k(j) = T_k(j - q) + sum_{m = 1..q} w^{k (t + (m - 1) L)} S_k(j - q + m)      w = exp(2 pi i / 1024)
+//     S_k(j) = sum over the whole callback,   T_k(j) = w^{-k c} (S_k(j) - H_k(j)),   c = L - t
+//     H_k(j) = sum over the first c samples of the callback (its "head")
+//
+// (the conjugate DFT kernel: same magnitudes).  Every sample is therefore multiplied by its
+// twiddles once, instead of once per ring that contains it (about 1024 / L times in a kernel that
+// evaluates each ring on its own).  Callbacks before the stream contribute zeros (spectrum.rs:50-51).
+//
+// A row of 16 lanes owns one callback per iteration (four callbacks per wavefront and
+// iteration); lane l holds the samples 128 p + 8 l + m of it (p < 5, m < 8), so every load
+// instruction covers 256 contiguous bytes per row (16-byte loads at 2-byte-aligned addresses),
+// 640 samples in all.  Twiddles are compile-time constants w^{k (128 p + m)} times one rotation by the
+// lane's w^{8 k l}; DPP row reductions.  Samples of a lane that lie past the callback are removed
+// by per-lane masks computed once.  The head is a prefix of the callback: the accumulators as they
+// stand after the pieces that lie entirely inside it (a compile-time piece index, a lane
+// threshold) give a second, head-only row sum; the one 16-byte piece that straddles the cut is
+// finished at the end of the run, when lane i turns callback i's sums into value and decision and
+// adds that partial sum from the raw samples itself.
+// The amplitude gate (spectrum.rs:77-80) is the row maximum: the callback's own samples.
+#include "bd_internal.h"
+
+#include "bd_twiddles.inc"  // BD_LANE_C / BD_LANE_S [k - 1][l] = cos / sin (2 pi k 8 l / 1024)
+#include "bd_split_tw.inc" // BD_SP_C / BD_SP_S [k - 1][8 p + m] = cos / sin (2 pi k (128 p + m) / 1024)
+
+typedef short bd_short2 __attribute__((ext_vector_type(2)));
+
+static __device__ const float bd_cos1024[1024] = {
+#include "bd_cos1024.inc"
+};
+static __device__ const float bd_sin1024[1024] = {
+#include "bd_sin1024.inc"
+};
+
+#ifndef BD_SPLIT_RUN
+#define BD_SPLIT_RUN 64   // callbacks per wavefront task; four more LDS slots hold the callbacks before it
+#endif
+#ifndef BD_SPLIT_REM_MAX
+#define BD_SPLIT_REM_MAX 24 // remainders up to this many samples are summed at the end of the run (multiple of 8)
+#endif
+
+struct bd_split_args {
+    const int16_t *samples;
+    float         *values;
+    uint8_t       *flags;
+    uint64_t       stride, out_stride;
+    uint64_t       n_cb;            // callbacks per stream that this kernel evaluates: 0 .. n_cb - 1
+    uint64_t       n_tasks;
+    uint32_t       runs_per_stream, callback_len;
+    uint32_t       q, head_len, tail_len;
+    uint32_t       min_amp, include_dc;
+    float          divisor, threshold;
+};
+
+struct __attribute__((aligned(16))) bd_split_slot {
+    float re1, im1, re2, im2;       // S_k: the whole callback
+    float hre1, him1, hre2, him2;   // the pieces entirely inside the head
+    int   dc, hdc;
+    float amax, pad;
+};
+
+struct bd_split_acc {
+    float a1, b1, a2, b2;
+    int   dc;
+};
+
+__device__ __forceinline__ void bd_rot(float &re, float &im, int idx)
+{
+    const float c = bd_cos1024[idx & (BD_RING_LEN - 1)], s = bd_sin1024[idx & (BD_RING_LEN - 1)];
+    const float r = re * c - im * s, i = re * s + im * c;
+    re = r; im = i;
+}
+
+typedef unsigned int bd_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+
+// One dword (two samples) into the running sums; TW = index of the first sample's twiddle in BD_SP_*.
+template <int NK, int TW>
+__device__ __forceinline__ void bd_split_dword(int v, bd_split_acc &x, float &amax)
+{
+    const float x0 = (float)(short)(v & 0xffff);
+    const float x1 = (float)(short)(v >> 16);
+    x.dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, x.dc, false);
+    amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+    if (NK >= 1) {
+        x.a1 = __builtin_fmaf(x0, BD_SP_C[0][TW], x.a1); x.b1 = __builtin_fmaf(x0, BD_SP_S[0][TW], x.b1);
+        x.a1 = __builtin_fmaf(x1, BD_SP_C[0][TW + 1], x.a1); x.b1 = __builtin_fmaf(x1, BD_SP_S[0][TW + 1], x.b1);
+    }
+    if (NK >= 2) {
+        x.a2 = __builtin_fmaf(x0, BD_SP_C[1][TW], x.a2); x.b2 = __builtin_fmaf(x0, BD_SP_S[1][TW], x.b2);
+        x.a2 = __builtin_fmaf(x1, BD_SP_C[1][TW + 1], x.a2); x.b2 = __builtin_fmaf(x1, BD_SP_S[1][TW + 1], x.b2);
+    }
+}
+
+// The first `m` (< 8 * N8) samples at `p` (2-byte aligned) as a sum anchored at p[0]; twiddles w^{k i}.
+template <int NK, int N8>
+__device__ __forceinline__ void bd_split_partial(const int16_t *p, int m, bd_split_acc &x, float &amax)
+{
+#pragma unroll
+    for (int u = 0; u < N8; u++) {
+        if (8 * u >= m) break;          // wave-uniform
+        const bd_u32x4_a2 v4 = *reinterpret_cast<const bd_u32x4_a2 *>(p + 8 * u);
+        const unsigned w[4] = {v4.x, v4.y, v4.z, v4.w};
+        bd_split_acc y;                 // this unit, anchored at its own first sample
+        y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int i = 8 * u + 2 * d;
+            const unsigned keep = (i + 1 < m) ? 0xffffffffu : ((i < m) ? 0x0000ffffu : 0u);
+            const int v = (int)(w[d] & keep);
+            if (d == 0) bd_split_dword<NK, 0>(v, y, amax);
+            else if (d == 1) bd_split_dword<NK, 2>(v, y, amax);
+            else if (d == 2) bd_split_dword<NK, 4>(v, y, amax);
+            else bd_split_dword<NK, 6>(v, y, amax);
+        }
+        bd_rot(y.a1, y.b1, 1 * 8 * u);
+        bd_rot(y.a2, y.b2, 2 * 8 * u);
+        x.a1 += y.a1; x.b1 += y.b1; x.a2 += y.a2; x.b2 += y.b2; x.dc += y.dc;
+    }
+}
+
+// PSTAR: index of the 128-sample group that holds the end of the head (head_len / 128).
+// PL: index of the group that holds the end of the callback (callback_len / 128): the groups
+// before it are whole in every lane, the groups after it are not read at all.
+// REM: the samples of group PL (the callback's remainder, at most BD_SPLIT_REM_MAX) stay out of
+// the main loop, which then has no masks and one piece less per lane; lane i adds the remainder of
+// callback i from the raw samples at the end of the run.  Otherwise group PL is one more, masked piece.
+// STAGED: callback lengths that are not multiples of four samples put most rows at addresses that
+// are not 8-byte aligned, where 16-byte global loads run at 80 % of their aligned rate (measured:
+// 4.2 TB/s for odd lengths, 4.7 for 4 k + 2, 5.2 for multiples of four).  Such lengths copy the
+// iteration's four callbacks to LDS as they lie in memory (aligned, contiguous 16-byte units),
+// and the lanes pick their pieces from there: a 16-byte LDS read at the dword below the piece,
+// one more dword, and a funnel shift by 16 bits in the rows that start on an odd sample.
+template <int NK, int PSTAR, int PL, bool STAGED, bool REM>
+__global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
+{
+    constexpr int PIECES = REM ? PL : PL + 1;
+    constexpr int LOADS = PL == 4 ? 6 : 5;            // 64 x LOADS units of 16 bytes hold four callbacks
+    constexpr int NBUF = STAGED ? LOADS : PIECES;
+    __shared__ bd_split_slot lds_slots[4][BD_SPLIT_RUN + 4];
+    __shared__ __attribute__((aligned(16))) uint4 lds_stage[STAGED ? 4 : 1][STAGED ? 64 * LOADS + 2 : 1];
+
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, l = lane & 15;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t task = bd_block_index() * 4 + wave;
+    if (task >= a.n_tasks) return;
+    const uint64_t s = task / a.runs_per_stream;
+    const int64_t j0 = (int64_t)(task - s * a.runs_per_stream) * BD_SPLIT_RUN;
+    const int64_t left = (int64_t)a.n_cb - j0;
+    const int n_win = left < BD_SPLIT_RUN ? (int)left : BD_SPLIT_RUN;
+    const int n_it = (n_win + 3) / 4;
+    const int it_begin = j0 > 0 ? -1 : 0;   // the q callbacks before the run (q <= 4); none before the stream
+    const int16_t *sp = a.samples + s * a.stride;
+    const int64_t L = a.callback_len;
+    bd_split_slot *slots = lds_slots[wave];
+
+    // ---- what a lane's place inside its callback fixes, once ----
+    unsigned mask[4];    // dword d of the masked piece holds samples 128 PL + 8 l + 2 d, + 1
+    const int o_last = 128 * PL + 8 * l;
+    // a masked piece that lies past the callback reads the lane's first piece instead
+    const int off_last = o_last < (int)L ? o_last : 8 * l;
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+        mask[d] = (o_last + 2 * d + 1 < (int)L) ? 0xffffffffu : ((o_last + 2 * d < (int)L) ? 0x0000ffffu : 0u);
+    const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
+    const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
+    // the head ends inside group PSTAR: there the lanes below `lstar` lie entirely inside it
+    const int c = (int)a.head_len;
+    const int lstar = (c - 128 * PSTAR) >> 3;
+    const bool below = l < lstar;
+
+    const int64_t j_last = j0 + n_win - 1;
+    // the staged copy never reaches past the stream's last callback (index n_cb, not evaluated here)
+    const uintptr_t limit_addr = (uintptr_t)(sp + ((int64_t)a.n_cb + 1) * L);
+    uint4 A[NBUF], B[NBUF];
+    auto load = [&](uint4 (&d)[NBUF], int it) {
+        if (STAGED) {
+            // callbacks jb .. jb + 3 (those up to j_last) as 16-byte units from the unit that holds
+            // the first sample of callback jb
+            const int64_t jb = j0 + 4 * (int64_t)it;
+            const int64_t je = jb + 3 < j_last ? jb + 3 : j_last;
+            const uintptr_t base = (uintptr_t)(sp + jb * L) & ~(uintptr_t)15;
+            uintptr_t end = (uintptr_t)(sp + (je + 1) * L);
+            end = end < limit_addr ? end : limit_addr;
+            const int n_units = (int)((end - base + 15) >> 4);
+            const int whole = (int)((limit_addr - base) >> 4);      // units that end at or before the limit
+            const int n_load = n_units < whole ? n_units : whole;
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) {
+                const int u = lane + 64 * i;
+                d[i] = make_uint4(0, 0, 0, 0);
+                if (u < n_load) d[i] = bd_load_stream16(reinterpret_cast<const uint4 *>(base) + u);
+            }
+        } else {
+            int64_t jj = j0 + 4 * (int64_t)it + g;
+            jj = jj < j_last ? jj : j_last;                     // stand-in rows of the last iteration
+            jj = jj < 0 ? 0 : jj;
+            const int16_t *cp = sp + jj * L;
+#pragma unroll
+            for (int p = 0; p < PIECES; p++) {
+                const bd_u32x4_a2 v = __builtin_nontemporal_load(
+                    reinterpret_cast<const bd_u32x4_a2 *>(cp + (p < PL ? 128 * p + 8 * l : off_last)));
+                d[p] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    auto compute = [&](const uint4 (&d)[PIECES], int it) {
+        bd_split_acc x;
+        x.a1 = x.b1 = x.a2 = x.b2 = 0.f; x.dc = 0;
+        bd_split_acc h_before = x, h_after = x;   // accumulators before / after the pieces of group PSTAR
+        float amax = 0.f;
+#pragma unroll
+        for (int p = 0; p < PIECES; p++) {
+            if (p == PSTAR) h_before = x;
+            const unsigned w[4] = {d[p].x, d[p].y, d[p].z, d[p].w};
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int v = (int)(p < PL ? w[qq] : (w[qq] & mask[qq]));
+                const float x0 = (float)(short)(v & 0xffff);
+                const float x1 = (float)(short)(v >> 16);
+                const int i0 = 8 * p + 2 * qq, i1 = i0 + 1;
+                x.dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, x.dc, false);
+                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+                if (NK >= 1) {
+                    x.a1 = __builtin_fmaf(x0, BD_SP_C[0][i0], x.a1); x.b1 = __builtin_fmaf(x0, BD_SP_S[0][i0], x.b1);
+                    x.a1 = __builtin_fmaf(x1, BD_SP_C[0][i1], x.a1); x.b1 = __builtin_fmaf(x1, BD_SP_S[0][i1], x.b1);
+                }
+                if (NK >= 2) {
+                    x.a2 = __builtin_fmaf(x0, BD_SP_C[1][i0], x.a2); x.b2 = __builtin_fmaf(x0, BD_SP_S[1][i0], x.b2);
+                    x.a2 = __builtin_fmaf(x1, BD_SP_C[1][i1], x.a2); x.b2 = __builtin_fmaf(x1, BD_SP_S[1][i1], x.b2);
+                }
+            }
+            if (p == PSTAR) h_after = x;
+        }
+        // the pieces of this lane that lie entirely inside the head
+        bd_split_acc h;
+        h.a1 = below ? h_after.a1 : h_before.a1; h.b1 = below ? h_after.b1 : h_before.b1;
+        h.a2 = below ? h_after.a2 : h_before.a2; h.b2 = below ? h_after.b2 : h_before.b2;
+        h.dc = below ? h_after.dc : h_before.dc;
+        // (a + i b) w^{8 k l}: sums anchored at the callback's first sample
+        bd_split_slot r;
+        r.re1 = r.im1 = r.re2 = r.im2 = r.hre1 = r.him1 = r.hre2 = r.him2 = 0.f;
+        if (NK >= 1) {
+            r.re1 = bd_row_sum(x.a1 * lc1 - x.b1 * ls1); r.im1 = bd_row_sum(x.a1 * ls1 + x.b1 * lc1);
+            r.hre1 = bd_row_sum(h.a1 * lc1 - h.b1 * ls1); r.him1 = bd_row_sum(h.a1 * ls1 + h.b1 * lc1);
+        }
+        if (NK >= 2) {
+            r.re2 = bd_row_sum(x.a2 * lc2 - x.b2 * ls2); r.im2 = bd_row_sum(x.a2 * ls2 + x.b2 * lc2);
+            r.hre2 = bd_row_sum(h.a2 * lc2 - h.b2 * ls2); r.him2 = bd_row_sum(h.a2 * ls2 + h.b2 * lc2);
+        }
+        r.dc = bd_row_sum(x.dc);
+        r.hdc = bd_row_sum(h.dc);
+        r.amax = bd_row_max(amax);
+        r.pad = 0.f;
+        const int slot = 4 * it + g + 4;   // callback j0 - 4 + slot
+        if (l == 0) slots[slot] = r;
+    };
+    auto run = [&](const uint4 (&d)[NBUF], int it) {
+        if constexpr (STAGED) {
+            uint4 *stage = lds_stage[wave];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) stage[lane + 64 * i] = d[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int64_t jb = j0 + 4 * (int64_t)it;
+            int64_t jj = jb + g;
+            jj = jj < j_last ? jj : j_last;
+            // byte offset of the row's first sample inside the staged copy
+            const unsigned row_off = (unsigned)(((uintptr_t)(sp + jb * L) & 15) + (uintptr_t)((jj - jb) * L * 2));
+            const unsigned sh = (row_off & 2) ? 16u : 0u;
+            const char *sb = reinterpret_cast<const char *>(stage) + (row_off & ~3u);
+            uint4 pc[PIECES];
+#pragma unroll
+            for (int p = 0; p < PIECES; p++) {
+                const unsigned po = (unsigned)(2 * (p < PL ? 128 * p + 8 * l : off_last));
+                typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(sb + po);
+                const unsigned e = *reinterpret_cast<const unsigned *>(sb + po + 16);
+                pc[p].x = __builtin_amdgcn_alignbit(v.y, v.x, sh);
+                pc[p].y = __builtin_amdgcn_alignbit(v.z, v.y, sh);
+                pc[p].z = __builtin_amdgcn_alignbit(v.w, v.z, sh);
+                pc[p].w = __builtin_amdgcn_alignbit(e, v.w, sh);
+            }
+            compute(pc, it);
+        } else {
+            compute(d, it);
+        }
+    };
+
+    int it = it_begin;
+    load(A, it);
+    for (; it + 2 < n_it; it += 2) {
+        load(B, it + 1);
+        run(A, it);
+        load(A, it + 2);
+        run(B, it + 1);
+    }
+    if (it + 1 < n_it) {
+        load(B, it + 1);
+        run(A, it);
+        run(B, it + 1);
+    } else {
+        run(A, it);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- end of the run: slot i holds callback j0 - 4 + i ----
+    if (REM) {
+        // the callbacks' remainders, samples 128 PL .. L - 1, from memory (the 16-byte loads may reach up to
+        // seven samples into the next callback, which exists: the stream's last one is not evaluated here)
+        for (int sidx = lane + (it_begin < 0 ? 0 : 4); sidx < n_win + 4; sidx += 64) {
+            const int64_t jr = j0 - 4 + sidx;
+            bd_split_acc y;
+            y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
+            float ramax = 0.f;
+            bd_split_partial<NK, BD_SPLIT_REM_MAX / 8>(sp + jr * L + 128 * PL, (int)L - 128 * PL, y, ramax);
+            bd_rot(y.a1, y.b1, 1 * 128 * PL);
+            bd_rot(y.a2, y.b2, 2 * 128 * PL);
+            bd_split_slot S = slots[sidx];
+            S.re1 += y.a1; S.im1 += y.b1; S.re2 += y.a2; S.im2 += y.b2; S.dc += y.dc;
+            S.amax = fmaxf(S.amax, ramax);
+            slots[sidx] = S;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint64_t o0 = s * a.out_stride + (uint64_t)j0;
+    __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, (unsigned)n_win);
+    __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values ? a.values + o0 : nullptr, a.values ? (unsigned)n_win * 4u : 0u);
+    // lane i finishes callback j0 + i (slot i + 4)
+    for (int i = lane; i < n_win; i += 64) {
+        const int64_t jj = j0 + i;
+        const int q = (int)a.q, t = (int)a.tail_len;
+        float xr1 = 0.f, xi1 = 0.f, xr2 = 0.f, xi2 = 0.f;
+        int xdc = 0;
+        const int64_t jt = jj - q;                          // the callback whose tail opens the ring
+        if (jt >= 0 && t > 0) {
+            const bd_split_slot T = slots[i + 4 - q];
+            // the piece that straddles the cut: its first m samples belong to the head
+            const int m = c & 7;
+            bd_split_acc hh;
+            hh.a1 = hh.b1 = hh.a2 = hh.b2 = 0.f; hh.dc = 0;
+            float unused = 0.f;
+            bd_split_partial<NK, 1>(sp + jt * L + (c - m), m, hh, unused);
+            // anchored at the piece's first sample, c - m: move to the callback's first sample
+            bd_rot(hh.a1, hh.b1, 1 * (c - m));
+            bd_rot(hh.a2, hh.b2, 2 * (c - m));
+            // T = w^{-k c} (S - H)
+            xr1 = T.re1 - (T.hre1 + hh.a1); xi1 = T.im1 - (T.him1 + hh.b1);
+            xr2 = T.re2 - (T.hre2 + hh.a2); xi2 = T.im2 - (T.him2 + hh.b2);
+            bd_rot(xr1, xi1, -1 * c);
+            bd_rot(xr2, xi2, -2 * c);
+            xdc = T.dc - (T.hdc + hh.dc);
+        }
+        for (int mm = 1; mm <= q; mm++) {
+            if (jt + mm < 0) continue;                      // before the stream: zeros
+            const bd_split_slot S = slots[i + 4 - q + mm];
+            float r1 = S.re1, i1 = S.im1, r2 = S.re2, i2 = S.im2;
+            const int off = t + (mm - 1) * (int)L;
+            bd_rot(r1, i1, 1 * off);
+            bd_rot(r2, i2, 2 * off);
+            xr1 += r1; xi1 += i1; xr2 += r2; xi2 += i2;
+            xdc += S.dc;
+        }
+        const float x_dc = (float)xdc;
+        float best = a.include_dc ? fabsf(x_dc) : 0.f;
+        if (NK >= 1) best = fmaxf(best, sqrtf(xr1 * xr1 + xi1 * xi1));
+        if (NK >= 2) best = fmaxf(best, sqrtf(xr2 * xr2 + xi2 * xi2));
+        const float value = (a.divisor == 0.f) ? best : best / a.divisor;
+        const float wmax = fminf(slots[i + 4].amax, 32767.f);   // window_stats.rs:47
+        const bool flag = (wmax >= (float)a.min_amp) && (value > a.threshold);
+        bd_store_stream_u8(rf, (unsigned)i, flag ? 1 : 0);
+        bd_store_stream_f32(rv, (unsigned)i * 4u, value);       // a zero-sized descriptor drops the store
+    }
+}
+
+bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
+{
+    // bins 0 .. 2, no Nyquist packing; lengths that a row of 16 lanes x 40 samples covers with most lanes
+    // busy, whose ring spans at most four callbacks and whose head ends in one of the first four groups
+    if (callback_len < 400 || callback_len >= 640) return false;
+    return plan.last_bin <= 2 && !(plan.dc_packs_nyquist && plan.first_bin == 0);
+}
+
+// Callbacks 0 .. n_cb_eval - 1 of every stream (the caller keeps the last callback of a stream out:
+// the 16-byte loads of a row may reach a few samples past the callback they belong to).
+int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64_t n_streams, uint64_t n_cb_eval,
+                             uint64_t stride, uint32_t callback_len, float *values, uint8_t *flags,
+                             uint64_t out_stride, hipStream_t st)
+{
+    if (n_cb_eval == 0 || n_streams == 0) return BD_OK;
+    bd_split_args a;
+    a.samples = samples; a.values = values; a.flags = flags;
+    a.stride = stride; a.out_stride = out_stride; a.n_cb = n_cb_eval;
+    const uint64_t runs = (n_cb_eval + BD_SPLIT_RUN - 1) / BD_SPLIT_RUN;
+    if (runs > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
+    a.runs_per_stream = (uint32_t)runs;
+    a.n_tasks = n_streams * runs;
+    a.callback_len = callback_len;
+    a.q = BD_RING_LEN / callback_len;
+    a.tail_len = BD_RING_LEN - a.q * callback_len;
+    a.head_len = callback_len - a.tail_len;
+    a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
+    a.divisor = plan.divisor; a.threshold = plan.threshold;
+    dim3 grid;
+    if (!bd_grid_dims((a.n_tasks + 3) / 4, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
+    // 400 .. 511 samples: two whole callbacks in the ring, the callback ends in group 3; 512 .. 639: one whole
+    // callback, the callback ends in group 4.  A remainder (samples past the last whole group) of at most 64
+    // samples stays out of the main loop.
+    const int pstar = (int)(a.head_len / 128), pl = (int)(callback_len / 128);
+    const bool rem = (int)callback_len - 128 * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
+    const bool staged = callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE");
+#define BD_SPLIT_GO(NK, PS, PLAST, RM) do { \
+        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM>), grid, dim3(256), 0, st, a); \
+        launched = true; } while (0)
+#define BD_SPLIT_PICK(NK) do { \
+        if (pl == 4 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 4, true); else BD_SPLIT_GO(NK, 0, 4, false); } \
+        else if (pl == 4 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 4, true); else BD_SPLIT_GO(NK, 1, 4, false); } \
+        else if (pl == 3 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 3, true); else BD_SPLIT_GO(NK, 1, 3, false); } \
+        else if (pl == 3 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 3, true); else BD_SPLIT_GO(NK, 2, 3, false); } \
+        else if (pl == 3 && pstar == 3) { BD_SPLIT_GO(NK, 3, 3, false); } } while (0)
+    bool launched = false;
+    if (plan.last_bin == 0) BD_SPLIT_PICK(0);
+    else if (plan.last_bin == 1) BD_SPLIT_PICK(1);
+    else BD_SPLIT_PICK(2);
+#undef BD_SPLIT_PICK
+#undef BD_SPLIT_GO
+    if (!launched) { bd_set_error("callback length %u outside the split kernel's range", callback_len); return BD_ERR_UNSUPPORTED; }
+    bd_set_last_kernel("bd_spectrum_split_kernel");
+    return bd_check_hip(hipGetLastError(), "launch bd_spectrum_split_kernel");
+}

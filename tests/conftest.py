@@ -50,3 +50,14 @@ def oracle_ext():
     from oracle import bd_oracle_ext
     bd_oracle_ext.lib()
     return bd_oracle_ext
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Band values are held to 1e-4 relative plus an absolute floor for bins near zero: say how many of the
+    compared values needed the floor."""
+    from tests import util
+    st = util.FLOOR_STATS
+    if st["values"]:
+        terminalreporter.write_line(
+            f"band values compared: {st['values']}; passed only through the absolute floor: {st['needed_floor']} "
+            f"(largest reference value among them: {st['largest_ref_needing_floor']:.3f}; decision threshold 2.1e6)")

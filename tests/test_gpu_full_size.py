@@ -42,7 +42,7 @@ def test_spectrum_hop512_16384_streams(bd, oracle):
         row = buf[s, :n].cpu().numpy()
         v, c, beats = oracle.run_stream(oracle.KIND_SPECTRUM, SR, row, 512, full=True)
         got = res.values[s].cpu().numpy()
-        assert (np.abs(got - v) <= util.value_tolerance(v, 32768, 3)).all(), s
+        assert util.values_close(got, v, 32768, 3).all(), s
         adjacent = util.threshold_adjacent(v, 2.1e6)
         assert ((res.flags[s].cpu().numpy() == c) | adjacent).all(), s
         if not adjacent.any():
@@ -93,7 +93,8 @@ def test_extension_batches(bd, oracle_ext):
 
 
 @pytest.mark.parametrize("kind_name,L,sr,kernel", [
-    ("Spectrum", 441, SR, "bd_spectrum_g63_kernel"), ("Spectrum", 450, SR, "bd_spectrum_window_kernel"), ("Spectrum", 480, SR, "bd_spectrum_granule_kernel"),
+    ("Spectrum", 441, SR, "bd_spectrum_g63_kernel"), ("Spectrum", 450, SR, "bd_spectrum_split_kernel"), ("Spectrum", 529, SR, "bd_spectrum_split_kernel"),
+    ("Spectrum", 700, SR, "bd_spectrum_window_kernel"), ("Spectrum", 480, SR, "bd_spectrum_granule_kernel"),
     ("Spectrum", 512, 16000, "bd_spectrum_granule_kernel"), ("Spectrum", 441, 22050, "bd_spectrum_window_kernel"),
     ("LPF", 441, SR, "bd_lpf_window_kernel"), ("LPF", 1000, SR, "bd_lpf_window_kernel")])
 def test_other_lengths_and_rates_at_4096_streams(bd, oracle, kind_name, L, sr, kernel):
@@ -118,7 +119,7 @@ def test_other_lengths_and_rates_at_4096_streams(bd, oracle, kind_name, L, sr, k
             assert np.array_equal(got_v, v) and np.array_equal(got_c, c), s
             assert res.beats(s) == beats, s
         else:
-            assert (np.abs(got_v - v) <= util.value_tolerance(v, 32768, div)).all(), s
+            assert util.values_close(got_v, v, 32768, div).all(), s
             adjacent = util.threshold_adjacent(v, 2.1e6)
             assert ((got_c == c) | adjacent).all(), s
             if not adjacent.any():

@@ -70,8 +70,7 @@ def test_random_shapes_against_the_oracle(bd, oracle, seed):
         else:
             nb, _, _ = oracle.bin_range(sr, p)
             div = {0: nb, 1: 1024, 2: 0}[p.spectrum_divisor]
-            tol = util.value_tolerance(ref_v, np.abs(x.astype(np.int32)).max(), div)
-            assert (np.abs(got_v.astype(np.float64) - ref_v) <= tol).all(), ctx
+            assert util.values_close(got_v, ref_v, np.abs(x.astype(np.int32)).max(), div).all(), ctx
             adjacent = util.threshold_adjacent(ref_v, p.spectrum_threshold)
             assert not ((got_c != ref_c) & ~adjacent).any(), ctx
         if (got_c == ref_c).all():

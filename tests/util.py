@@ -28,6 +28,27 @@ def value_tolerance(ref_values, max_abs_sample, divisor):
     return REL_TOL * np.abs(ref_values) + REL_TOL * max(float(max_abs_sample), 1.0) / div
 
 
+# How often the absolute floor was what let a value pass (printed at the end of a test session):
+# the relative bound alone is the stated tolerance, the floor only covers bins near zero.
+FLOOR_STATS = {"values": 0, "needed_floor": 0, "largest_ref_needing_floor": 0.0}
+
+
+def values_close(got, ref_values, max_abs_sample, divisor):
+    """Boolean array: |got - ref| within value_tolerance(); counts the values that pass only
+    through the absolute floor."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref_values, dtype=np.float64)
+    err = np.abs(got - ref)
+    ok = err <= value_tolerance(ref_values, max_abs_sample, divisor)
+    floor_only = ok & (err > REL_TOL * np.abs(ref))
+    FLOOR_STATS["values"] += int(ok.size)
+    FLOOR_STATS["needed_floor"] += int(floor_only.sum())
+    if floor_only.any():
+        FLOOR_STATS["largest_ref_needing_floor"] = max(FLOOR_STATS["largest_ref_needing_floor"],
+                                                       float(np.abs(ref[floor_only]).max()))
+    return ok
+
+
 def threshold_adjacent(ref_values, threshold):
     """Callbacks whose reference value is within REL_TOL of the threshold: the
     only ones whose decision may legitimately differ."""
