@@ -220,7 +220,9 @@ __device__ __forceinline__ void bd_wave_lds_sync()
 }
 
 // HQ: hop in quarters of the frame (2: hop = N / 2, 1: hop = N / 4).
-template <int E, int HQ>
+// PWR: flux and band energy from the squared magnitudes (no square roots: a sixth of the
+// frame's instructions are the correctly rounded roots).
+template <int E, int HQ, bool PWR>
 __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 {
     using C = bd_fft_cfg<E>;
@@ -383,7 +385,9 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
             x_min = fminf(x_min, xs_m);
         }
         // magnitudes; a wavefront with a tiny or zero argument takes the library square root
-        if (__builtin_amdgcn_ballot_w64(x_min < 0x1p-96f) != 0) {
+        if (PWR) {
+            // flux of the power spectrum: xs stays 4 |X|^2
+        } else if (__builtin_amdgcn_ballot_w64(x_min < 0x1p-96f) != 0) {
 #pragma unroll
             for (int t = 0; t < E; t++) xs[t] = __builtin_sqrtf(xs[t]);
             xs_m = __builtin_sqrtf(xs_m);
@@ -393,10 +397,10 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
             xs_m = bd_sqrt_rn_normal(xs_m);
         }
         // lane l sums its bins l, l + 64, ... in ascending order (zero terms of the band sum skipped)
-        float flux_p = 0.f, band_p = (uint32_t)lane <= a.kmax ? xs[0] * xs[0] : 0.f;
+        float flux_p = 0.f, band_p = (uint32_t)lane <= a.kmax ? (PWR ? xs[0] : xs[0] * xs[0]) : 0.f;
         if (__builtin_expect(a.kmax >= 64, 0)) {
 #pragma unroll
-            for (int t = 1; t < E; t++) band_p += (uint32_t)(lane + 64 * t) <= a.kmax ? xs[t] * xs[t] : 0.f;
+            for (int t = 1; t < E; t++) band_p += (uint32_t)(lane + 64 * t) <= a.kmax ? (PWR ? xs[t] : xs[t] * xs[t]) : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < E; t++) {
@@ -407,10 +411,10 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
         if (lane == 0) {
             const float d = xs_m - prev_m;
             flux_p += d > 0.f ? d : 0.f;
-            band_p += (uint32_t)M <= a.kmax ? xs_m * xs_m : 0.f;
+            band_p += (uint32_t)M <= a.kmax ? (PWR ? xs_m : xs_m * xs_m) : 0.f;
         }
         prev_m = xs_m;
-        const float flux = 0.5f * bd_butterfly_sum_lane63(flux_p);
+        const float flux = (PWR ? 0.25f : 0.5f) * bd_butterfly_sum_lane63(flux_p);
         const float band = 0.25f * bd_butterfly_sum_lane63(band_p);
         // lane i keeps the results of frame f0 + i (run_frames <= 64)
         const float flux_u = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(flux), 63));
@@ -456,11 +460,15 @@ __device__ __forceinline__ void bd_stft_flux_body(const bd_onset_args &a)
 
 // N = 2048 asks for three waves per SIMD (168 registers); N = 1024 leaves the
 // register count to the compiler (about 110, four waves per SIMD).
-template <int E, int HQ> __global__ void bd_stft_flux_kernel(bd_onset_args a);
-template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 2>(bd_onset_args a) { bd_stft_flux_body<16, 2>(a); }
-template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 1>(bd_onset_args a) { bd_stft_flux_body<16, 1>(a); }
-template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 2>(bd_onset_args a) { bd_stft_flux_body<8, 2>(a); }
-template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 1>(bd_onset_args a) { bd_stft_flux_body<8, 1>(a); }
+template <int E, int HQ, bool PWR> __global__ void bd_stft_flux_kernel(bd_onset_args a);
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 2, false>(bd_onset_args a) { bd_stft_flux_body<16, 2, false>(a); }
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 1, false>(bd_onset_args a) { bd_stft_flux_body<16, 1, false>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 2, false>(bd_onset_args a) { bd_stft_flux_body<8, 2, false>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 1, false>(bd_onset_args a) { bd_stft_flux_body<8, 1, false>(a); }
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 2, true>(bd_onset_args a) { bd_stft_flux_body<16, 2, true>(a); }
+template <> __global__ __launch_bounds__(256, 3) void bd_stft_flux_kernel<16, 1, true>(bd_onset_args a) { bd_stft_flux_body<16, 1, true>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 2, true>(bd_onset_args a) { bd_stft_flux_body<8, 2, true>(a); }
+template <> __global__ __launch_bounds__(256) void bd_stft_flux_kernel<8, 1, true>(bd_onset_args a) { bd_stft_flux_body<8, 1, true>(a); }
 
 // ---- peak picking -----------------------------------------------------------
 // One wavefront per stream.  Lane = frame: moving mean of flux[j-W .. j+W]
@@ -545,6 +553,7 @@ extern "C" void bd_onset_default_params(bd_onset_params *p)
     p->fft_len = 2048; p->hop = 1024; p->window = 1; p->band_max_hz = 90.0f;
     p->mean_frames = 8; p->max_frames = 3; p->delta = 0.0f; p->lambda = 1.5f; p->min_gap_ms = 100;
     p->use_median = 0;
+    p->flux_power = 0;
 }
 
 extern "C" uint64_t bd_onset_frames(uint64_t n_samples, uint32_t fft_len, uint32_t hop)
@@ -595,13 +604,12 @@ extern "C" int bd_onset_stft(uint32_t sampling_rate, const bd_onset_params *p, c
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)hip_stream;
     const bool half = p->hop == p->fft_len / 2;
-    if (p->fft_len == 2048) {
-        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<16, 2>), grid_dims, dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((bd_stft_flux_kernel<16, 1>), grid_dims, dim3(256), 0, s, a);
-    } else {
-        if (half) hipLaunchKernelGGL((bd_stft_flux_kernel<8, 2>), grid_dims, dim3(256), 0, s, a);
-        else      hipLaunchKernelGGL((bd_stft_flux_kernel<8, 1>), grid_dims, dim3(256), 0, s, a);
-    }
+#define BD_STFT_LAUNCH(EE, HH) do { \
+        if (p->flux_power) hipLaunchKernelGGL((bd_stft_flux_kernel<EE, HH, true>), grid_dims, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((bd_stft_flux_kernel<EE, HH, false>), grid_dims, dim3(256), 0, s, a); } while (0)
+    if (p->fft_len == 2048) { if (half) BD_STFT_LAUNCH(16, 2); else BD_STFT_LAUNCH(16, 1); }
+    else { if (half) BD_STFT_LAUNCH(8, 2); else BD_STFT_LAUNCH(8, 1); }
+#undef BD_STFT_LAUNCH
     bd_set_last_kernel("bd_stft_flux_kernel");
     return bd_check_hip(hipGetLastError(), "launch bd_stft_flux_kernel");
 }

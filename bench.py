@@ -62,6 +62,9 @@ WORKLOADS = {
     "onset_2048": ("Onset", 1024, 4096, 300,
                    "Extension mode: 4,096 synthetic 5-min tracks per GPU, 2048-pt Hann STFT hop 1024, spectral flux + "
                    "band energy + adaptive peak picking"),
+    "onset_2048_power": ("Onset", 1024, 4096, 300,
+                         "Extension mode: 4,096 synthetic 5-min tracks per GPU, 2048-pt Hann STFT hop 1024, flux of the "
+                         "power spectrum (no square roots) + band energy + adaptive peak picking"),
     "biquad": ("Biquad", 1024, 4096, 60,
                "Extension mode: carried-state biquad envelope (120 Hz low-pass as a chunked scan), 4,096 synthetic "
                "click-track streams x 60 s @ 44.1 kHz, 1024-sample decision windows + refractory"),
@@ -79,7 +82,8 @@ WORKLOADS = {
                            "peak picking"),
 }
 # FFT length of the onset workloads (callback_len is their hop)
-ONSET_FFT = {"onset_2048": 2048, "onset_1024": 1024, "onset_2048_hop512": 2048, "onset_2048_chunked": 2048}
+ONSET_FFT = {"onset_2048": 2048, "onset_1024": 1024, "onset_2048_hop512": 2048, "onset_2048_chunked": 2048,
+             "onset_2048_power": 2048}
 METRIC = {"Spectrum": "1024-pt STFT", "LPF": "lowpass windows", "Biquad": "carried-state biquad"}
 
 
@@ -216,7 +220,7 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
     bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=SEED, sampling_rate=sr)
     nfft = ONSET_FFT.get(workload, 0)
     if onset:
-        oparams = bd.OnsetParams.default(fft_len=nfft, hop=L)
+        oparams = bd.OnsetParams.default(fft_len=nfft, hop=L, flux_power=1 if workload.endswith("_power") else 0)
         n_cb = bd.onset_frames(n, nfft, L)               # frames per track
         max_beats = max(1, (n * 1000 // sr) // max(oparams.min_gap_ms, 1) + 1)
     else:
@@ -334,7 +338,7 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
         result["roofline"]["note"] = ("this kernel is limited by f32 VALU issue (a 2048-point FFT per 1024 new samples), "
                                       "not by HBM; the HBM fraction is reported for comparison with the other workloads")
         result["roofline"]["valu"] = _valu_roofline(streams, n_cb, nfft, k1_ms)
-    state = dict(kind_name=kind_name, samples=samples, values=values, flags=flags, count=count, idx=idx, ms=ms, n=n, L=L,
+    state = dict(flux_power=1 if workload.endswith("_power") else 0, kind_name=kind_name, samples=samples, values=values, flags=flags, count=count, idx=idx, ms=ms, n=n, L=L,
                  sr=sr, nfft=nfft, streams=streams, out_stride=out_stride)
     return result, state
 
@@ -614,7 +618,7 @@ def cpu_baseline_onset(state, n_streams):
     n, hop, sr, nfft = state["n"], state["L"], state["sr"], state["nfft"]
     host = state["samples"][:n_streams, :n].cpu().numpy()
     cores, info = _host_cpus()
-    p = ox.default_params(fft_len=nfft, hop=hop)
+    p = ox.default_params(fft_len=nfft, hop=hop, flux_power=state.get("flux_power", 0))
 
     def one(row):
         flux, _ = ox.onset_stft(row, sr, p)
@@ -708,7 +712,7 @@ def main() -> None:
         torch.cuda.empty_cache()                   # the chunked pass needs 217 GB of the 288
         also = []
         if also_mode == "all":
-            for w in ("spectrum_1024", "lpf", "biquad", "onset_2048"):
+            for w in ("spectrum_1024", "spectrum_529", "lpf", "biquad", "onset_2048", "onset_2048_power"):
                 r, st_ = run_resident(ctx, w, 3, 1)
                 del st_
                 gc.collect()

@@ -55,6 +55,7 @@ pub struct bd_onset_params {
     pub lambda: f32,
     pub min_gap_ms: u32,
     pub use_median: u32,
+    pub flux_power: u32,
 }
 
 #[repr(C)]

@@ -36,6 +36,9 @@
  *        flux[j] = 0.5 * sum_k max(0, m2_j[k] - m2_{j-1}[k])     (m2_{-1} = 0)
  *        band_energy[j] = 0.25 * sum_{k <= kmax} m2_j[k]^2        (terms fma-free: m * m)
  *    and |X[k]| = 0.5 * m2[k] where a magnitude is reported.
+ * 6. With flux_power set no square root is taken: p2[k] = fma(Y.re, Y.re, Y.im * Y.im) (= 4 |X[k]|^2),
+ *        flux[j] = 0.25 * sum_k max(0, p2_j[k] - p2_{j-1}[k])    (p2_{-1} = 0)
+ *        band_energy[j] = 0.25 * sum_{k <= kmax} p2_j[k]
  */
 #include "bd_oracle_ext.h"
 
@@ -57,6 +60,7 @@ void bdo_onset_default_params(bdo_onset_params *p)
     p->lambda = 1.5f;
     p->min_gap_ms = 100;
     p->use_median = 0;
+    p->flux_power = 0;
 }
 
 size_t bdo_onset_frames(size_t n_samples, uint32_t fft_len, uint32_t hop)
@@ -77,8 +81,8 @@ static const float (*tw_table(uint32_t n))[2]
 
 static int log2u(uint32_t v) { int r = 0; while ((1u << r) < v) r++; return r; }
 
-/* m2[k] = 2 |X[k]| of one frame (items 1 - 4) */
-static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
+/* m2[k] = 2 |X[k]| of one frame (items 1 - 4), or its square 4 |X[k]|^2 (item 6) */
+static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *mag, int power)
 {
     if (n != 1024 && n != 2048) return -1;
     const float (*tw)[2] = tw_table(n);
@@ -133,7 +137,7 @@ static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *m
         const float xr = fmaf(-s, dr, fmaf(c, di, er));
         const float xi = fmaf(-s, di, fmaf(-c, dr, ei));
         const float xi2 = xi * xi;
-        mag[k] = sqrtf(fmaf(xr, xr, xi2));
+        mag[k] = power ? fmaf(xr, xr, xi2) : sqrtf(fmaf(xr, xr, xi2));
     }
     free(re); free(im);
     return 0;
@@ -141,7 +145,7 @@ static int rfft_mag2(const int16_t *frame, uint32_t n, uint32_t window, float *m
 
 int bdo_ext_rfft_mag(const int16_t *frame, uint32_t n, uint32_t window, float *mag)
 {
-    if (rfft_mag2(frame, n, window, mag) != 0) return -1;
+    if (rfft_mag2(frame, n, window, mag, 0) != 0) return -1;
     for (uint32_t k = 0; k <= n / 2; k++) mag[k] = 0.5f * mag[k];
     return 0;
 }
@@ -194,13 +198,14 @@ int bdo_onset_stft(const int16_t *samples, size_t n_samples, uint32_t sampling_r
     uint32_t kmax = 0;
     for (uint32_t k = 0; k <= m; k++) { if ((float)k * res <= p->band_max_hz) kmax = k; else break; }
     for (size_t j = 0; j < frames; j++) {
-        rfft_mag2(samples + j * p->hop, n, p->window, cur);
+        const int power = p->flux_power != 0;
+        rfft_mag2(samples + j * p->hop, n, p->window, cur, power);
         if (flux) {
             for (uint32_t k = 0; k <= m; k++) { const float d = cur[k] - prev[k]; term[k] = d > 0.0f ? d : 0.0f; }
-            flux[j] = 0.5f * lane_sum(term, m);
+            flux[j] = (power ? 0.25f : 0.5f) * lane_sum(term, m);
         }
         if (band_energy) {
-            for (uint32_t k = 0; k <= m; k++) term[k] = k <= kmax ? cur[k] * cur[k] : 0.0f;
+            for (uint32_t k = 0; k <= m; k++) term[k] = k <= kmax ? (power ? cur[k] : cur[k] * cur[k]) : 0.0f;
             band_energy[j] = 0.25f * lane_sum(term, m);
         }
         float *t = prev; prev = cur; cur = t;

@@ -37,6 +37,7 @@ typedef struct bdo_onset_params {
     uint32_t min_gap_ms;   /* onsets closer than this to the previous one are dropped */
     uint32_t use_median;   /* 1: the threshold follows the median of flux[j-W .. j+W] (element c/2 of the
                               sorted window of c values) instead of the mean; W <= 32 */
+    uint32_t flux_power;   /* 1: flux (and band energy) from the squared magnitudes, no square roots */
 } bdo_onset_params;
 
 void   bdo_onset_default_params(bdo_onset_params *p);

@@ -24,6 +24,7 @@ class OnsetParams(C.Structure):
         ("lambda_", C.c_float),
         ("min_gap_ms", C.c_uint32),
         ("use_median", C.c_uint32),
+        ("flux_power", C.c_uint32),
     ]
 
 

@@ -47,6 +47,7 @@ def test_onset_random_shapes(bd, oracle_ext, seed):
         n_streams = int(rng.integers(1, 6))
         sr = int(rng.choice([44100, 48000, 22050]))
         kw = dict(fft_len=fft_len, hop=hop, window=int(rng.integers(0, 2)), use_median=int(rng.integers(0, 2)),
+                  flux_power=int(rng.integers(0, 2)),
                   mean_frames=int(rng.integers(0, 12)), max_frames=int(rng.integers(0, 5)),
                   min_gap_ms=int(rng.integers(0, 400)), band_max_hz=float(rng.choice([90.0, 200.0, 3000.0])))
         x = _signal(rng, n_streams, n)

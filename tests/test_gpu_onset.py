@@ -42,12 +42,13 @@ def _streams(n_streams, n, seed=0):
 @pytest.mark.parametrize("window", [1, 0])
 @pytest.mark.parametrize("n", [2048 * 70 + 13, 2048 * 3, 2048])
 @pytest.mark.parametrize("hop_div", [2, 4])
-def test_flux_and_band_energy_bit_exact(bd, oracle_ext, fft_len, window, n, hop_div):
+@pytest.mark.parametrize("power", [0, 1])
+def test_flux_and_band_energy_bit_exact(bd, oracle_ext, fft_len, window, n, hop_div, power):
     rows = _streams(9, n, seed=fft_len + window)
     dev, host = _aligned_rows(rows)
     hop = fft_len // hop_div
-    p = bd.OnsetParams.default(fft_len=fft_len, hop=hop, window=window)
-    op = oracle_ext.default_params(fft_len=fft_len, hop=hop, window=window)
+    p = bd.OnsetParams.default(fft_len=fft_len, hop=hop, window=window, flux_power=power)
+    op = oracle_ext.default_params(fft_len=fft_len, hop=hop, window=window, flux_power=power)
     flux, band = bd.onset_stft(SR, dev, n_samples=n, params=p)
     flux, band = flux.cpu().numpy(), band.cpu().numpy()
     nf = oracle_ext.frames(n, fft_len, hop)
@@ -81,7 +82,8 @@ def test_onsets_match_definition(bd, oracle_ext, fft_len):
     for kw in (dict(), dict(hop=fft_len // 4), dict(hop=fft_len // 4, use_median=1, min_gap_ms=120),
                dict(mean_frames=3, max_frames=1, delta=1000.0, lambda_=1.2, min_gap_ms=250),
                dict(mean_frames=0, max_frames=0, delta=0.0, lambda_=0.5, min_gap_ms=0),
-               dict(use_median=1), dict(use_median=1, mean_frames=32, max_frames=2, lambda_=2.0, min_gap_ms=50)):
+               dict(use_median=1), dict(use_median=1, mean_frames=32, max_frames=2, lambda_=2.0, min_gap_ms=50),
+               dict(flux_power=1), dict(flux_power=1, hop=fft_len // 4, window=0)):
         p = bd.OnsetParams.default(fft_len=fft_len, **kw)
         op = oracle_ext.default_params(fft_len=fft_len, **kw)
         res = bd.onset_batch(SR, dev, n_samples=n, params=p)
