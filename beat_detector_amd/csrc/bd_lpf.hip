@@ -150,10 +150,14 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
         // only in the first line and hi < CHUNK only in the last.  A piece that reaches outside the
         // analysed samples of the stream -- possibly outside the buffer -- is gathered sample by
         // sample; pieces that merely reach into the neighbouring window are loaded whole.
+        // Positions are bytes from the stream's first sample plus that sample's address modulo SEG
+        // (equal to the address modulo SEG), and every load address is the kernel's argument plus an
+        // offset: global loads, which return in order, so that the next chunk's loads stay in flight.
         constexpr uint32_t SEG = CHUNK * 2;
-        const uintptr_t g_addr = reinterpret_cast<uintptr_t>(gp);
-        const uintptr_t s_begin = reinterpret_cast<uintptr_t>(a.samples + s * a.stride);
-        const uintptr_t s_end = s_begin + 2 * a.n_cb * (uint64_t)L;
+        const char *s_ptr = reinterpret_cast<const char *>(a.samples + s * a.stride);
+        const int64_t s_begin = (int64_t)(reinterpret_cast<uintptr_t>(s_ptr) & (SEG - 1));
+        const int64_t g_addr = s_begin + 2 * (int64_t)(j0 * L);
+        const int64_t s_end = s_begin + 2 * (int64_t)(a.n_cb * (uint64_t)L);
         const int lrow = lane / PIECES, piece = lane % PIECES;
         const uint32_t n_lines = (L + 2 * BD_LPF_CHUNK - 2) / BD_LPF_CHUNK; // lines a row can touch
         uint4 stage[PIECES];
@@ -163,17 +167,17 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
                 const uint32_t row = ROWS_PER_LOAD * i + lrow;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (row < rows) {
-                    const uintptr_t row_a = g_addr + 2 * (uint64_t)row * L, row_e = row_a + 2 * (uint64_t)L;
-                    const uintptr_t pa = (row_a & ~(uintptr_t)(SEG - 1)) + (uint64_t)ch * SEG + 16u * (uint32_t)piece;
+                    const int64_t row_a = g_addr + 2 * (int64_t)row * L, row_e = row_a + 2 * (int64_t)L;
+                    const int64_t pa = (row_a & ~(int64_t)(SEG - 1)) + (int64_t)ch * SEG + 16 * piece;
                     if (pa + 16 > row_a && pa < row_e) {
                         if (pa >= s_begin && pa + 16 <= s_end) {
-                            v = bd_load_stream16(reinterpret_cast<const void *>(pa));
+                            v = bd_load_stream16(s_ptr + (pa - s_begin));
                         } else {
                             unsigned w[4] = {0, 0, 0, 0};
                             for (uint32_t e = 0; e < 8; e++) {
-                                const uintptr_t ea = pa + 2 * e;
+                                const int64_t ea = pa + 2 * e;
                                 if (ea >= row_a && ea < row_e)
-                                    w[e >> 1] |= (unsigned)*reinterpret_cast<const uint16_t *>(ea) << (16 * (e & 1));
+                                    w[e >> 1] |= (unsigned)*reinterpret_cast<const uint16_t *>(s_ptr + (ea - s_begin)) << (16 * (e & 1));
                             }
                             v = make_uint4(w[0], w[1], w[2], w[3]);
                         }

@@ -127,6 +127,13 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
     // Lane 0 of each row parks the row's sums.  Combining neighbouring half-blocks into
     // callbacks, magnitudes, scaling and the decision happen once per run with all lanes busy
     // (bd_spec_finish) instead of on four lanes in every iteration.
+    // (The empty statement keeps the sums computed in every lane: moved into the branch of the one
+    // lane that stores them, the last step of each reduction is a lane move plus an add instead of
+    // one add that reads its operand through the lane rotation.)
+    if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1));
+    if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2));
+    if (NYQ) asm volatile("" :: "v"(r.ny));
+    asm volatile("" :: "v"(r.dc), "v"(r.amax));
     if (l == 0 && slot >= 0) slots[slot] = r;
 }
 

@@ -25,8 +25,10 @@
 // by per-lane masks computed once.  The head is a prefix of the callback: the accumulators as they
 // stand after the pieces that lie entirely inside it (a compile-time piece index, a lane
 // threshold) give a second, head-only row sum; the one 16-byte piece that straddles the cut is
-// finished at the end of the run, when lane i turns callback i's sums into value and decision and
-// adds that partial sum from the raw samples itself.
+// parked in LDS as it is, and finished at the end of the run, when lane i turns callback i's sums
+// into value and decision and adds that piece's partial sum itself.  (Reading the piece again from
+// memory at that point costs a whole cache line per callback: the streaming loads leave nothing in
+// L2.  Measured on 529-sample callbacks: 31 % more HBM traffic than the samples themselves.)
 // The amplitude gate (spectrum.rs:77-80) is the row maximum: the callback's own samples.
 #include "bd_internal.h"
 
@@ -48,6 +50,10 @@ static __device__ const float bd_sin1024[1024] = {
 #ifndef BD_SPLIT_REM_MAX
 #define BD_SPLIT_REM_MAX 24 // remainders up to this many samples are summed at the end of the run (multiple of 8)
 #endif
+// Wavefronts (tasks) per block.  The staged kernels that also park remainders hold 13.8 KB of LDS per
+// wavefront: in blocks of four, two blocks fit a CU (eight wavefronts); one by one, eleven do
+// (measured on 529-sample callbacks: 4.9 -> 5.3 TB/s).  The others lose a little in small blocks.
+__host__ __device__ constexpr int bd_split_waves(bool staged, bool rem) { return staged && rem ? 1 : 4; }
 
 struct bd_split_args {
     const int16_t *samples;
@@ -101,14 +107,15 @@ __device__ __forceinline__ void bd_split_dword(int v, bd_split_acc &x, float &am
     }
 }
 
-// The first `m` (< 8 * N8) samples at `p` (2-byte aligned) as a sum anchored at p[0]; twiddles w^{k i}.
+// The first `m` (< 8 * N8) samples of the 16-byte units at `units` as a sum anchored at the first
+// sample; twiddles w^{k i}.
 template <int NK, int N8>
-__device__ __forceinline__ void bd_split_partial(const int16_t *p, int m, bd_split_acc &x, float &amax)
+__device__ __forceinline__ void bd_split_partial(const uint4 *units, int m, bd_split_acc &x, float &amax)
 {
 #pragma unroll
     for (int u = 0; u < N8; u++) {
         if (8 * u >= m) break;          // wave-uniform
-        const bd_u32x4_a2 v4 = *reinterpret_cast<const bd_u32x4_a2 *>(p + 8 * u);
+        const uint4 v4 = units[u];
         const unsigned w[4] = {v4.x, v4.y, v4.z, v4.w};
         bd_split_acc y;                 // this unit, anchored at its own first sample
         y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
@@ -132,8 +139,9 @@ __device__ __forceinline__ void bd_split_partial(const int16_t *p, int m, bd_spl
 // PL: index of the group that holds the end of the callback (callback_len / 128): the groups
 // before it are whole in every lane, the groups after it are not read at all.
 // REM: the samples of group PL (the callback's remainder, at most BD_SPLIT_REM_MAX) stay out of
-// the main loop, which then has no masks and one piece less per lane; lane i adds the remainder of
-// callback i from the raw samples at the end of the run.  Otherwise group PL is one more, masked piece.
+// the main loop, which then has no masks and one piece less per lane: the first lanes of a row park
+// the remainder's 16-byte units in LDS, and lane i adds the remainder of callback i from there at the
+// end of the run.  Otherwise group PL is one more, masked piece.
 // STAGED: callback lengths that are not multiples of four samples put most rows at addresses that
 // are not 8-byte aligned, where 16-byte global loads run at 80 % of their aligned rate (measured:
 // 4.2 TB/s for odd lengths, 4.7 for 4 k + 2, 5.2 for multiples of four).  Such lengths copy the
@@ -141,18 +149,23 @@ __device__ __forceinline__ void bd_split_partial(const int16_t *p, int m, bd_spl
 // and the lanes pick their pieces from there: a 16-byte LDS read at the dword below the piece,
 // one more dword, and a funnel shift by 16 bits in the rows that start on an odd sample.
 template <int NK, int PSTAR, int PL, bool STAGED, bool REM>
-__global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
+__global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_split_kernel(bd_split_args a)
 {
+    constexpr int WAVES = bd_split_waves(STAGED, REM);
     constexpr int PIECES = REM ? PL : PL + 1;
     constexpr int LOADS = PL == 4 ? 6 : 5;            // 64 x LOADS units of 16 bytes hold four callbacks
-    constexpr int NBUF = STAGED ? LOADS : PIECES;
-    __shared__ bd_split_slot lds_slots[4][BD_SPLIT_RUN + 4];
-    __shared__ __attribute__((aligned(16))) uint4 lds_stage[STAGED ? 4 : 1][STAGED ? 64 * LOADS + 2 : 1];
+    constexpr int REM_UNITS = BD_SPLIT_REM_MAX / 8;
+    constexpr int NBUF = STAGED ? LOADS : (REM ? PIECES + 1 : PIECES);
+    constexpr int KEEP = REM ? 1 + REM_UNITS : 1;     // parked per callback: the head's last piece, the remainder
+    static_assert(PSTAR < PIECES, "the head ends inside a group of the main loop");
+    __shared__ bd_split_slot lds_slots[WAVES][BD_SPLIT_RUN + 4];
+    __shared__ __attribute__((aligned(16))) uint4 lds_keep[WAVES][BD_SPLIT_RUN + 4][KEEP];
+    __shared__ __attribute__((aligned(16))) uint4 lds_stage[STAGED ? WAVES : 1][STAGED ? 64 * LOADS + 2 : 1];
 
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, l = lane & 15;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t task = bd_block_index() * 4 + wave;
+    const uint64_t task = bd_block_index() * WAVES + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
     const int64_t j0 = (int64_t)(task - s * a.runs_per_stream) * BD_SPLIT_RUN;
@@ -163,6 +176,8 @@ __global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
     const int16_t *sp = a.samples + s * a.stride;
     const int64_t L = a.callback_len;
     bd_split_slot *slots = lds_slots[wave];
+    uint4 (*keep)[KEEP] = lds_keep[wave];
+    const int q_cb = (int)a.q;
 
     // ---- what a lane's place inside its callback fixes, once ----
     unsigned mask[4];    // dword d of the masked piece holds samples 128 PL + 8 l + 2 d, + 1
@@ -180,31 +195,49 @@ __global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
     const bool below = l < lstar;
 
     const int64_t j_last = j0 + n_win - 1;
-    // the staged copy never reaches past the stream's last callback (index n_cb, not evaluated here)
-    const uintptr_t limit_addr = (uintptr_t)(sp + ((int64_t)a.n_cb + 1) * L);
-    uint4 A[NBUF], B[NBUF];
+    // The staged copy counts bytes from `run_ptr`, the 16-byte line that holds the first sample this
+    // run reads (callback `cb0`): 32-bit arithmetic inside the loop, and every load address stays an
+    // offset from the kernel's argument (global loads, which return in order and leave the loads of
+    // the next iteration in flight while this one's are awaited).  It never reaches past the stream's
+    // last callback (index n_cb, not evaluated here): `limit_rel`.
+    const int64_t cb0 = it_begin < 0 ? j0 - q_cb : j0;
+    const unsigned L2 = 2u * (unsigned)L;
+    const unsigned m0 = (unsigned)(((int64_t)((uintptr_t)sp & 15) + cb0 * L * 2) & 15);
+    const char *run_ptr = reinterpret_cast<const char *>(sp) + (cb0 * L * 2 - (int64_t)m0);
+    const int64_t limit64 = (int64_t)m0 + ((int64_t)a.n_cb + 1 - cb0) * L * 2;
+    const unsigned limit_rel = limit64 < (1 << 24) ? (unsigned)limit64 : (1u << 24);
+    const int first_rel = (int)(j0 - cb0), last_rel = (int)(j_last - cb0);   // the run's callbacks, counted from cb0
+    uint4 A[NBUF];
+    uint4 B[STAGED ? 1 : NBUF];
     auto load = [&](uint4 (&d)[NBUF], int it) {
         if (STAGED) {
             // callbacks jb .. jb + 3 (those up to j_last) as 16-byte units from the unit that holds
             // the first sample of callback jb
-            const int64_t jb = j0 + 4 * (int64_t)it;
-            const int64_t je = jb + 3 < j_last ? jb + 3 : j_last;
-            const uintptr_t base = (uintptr_t)(sp + jb * L) & ~(uintptr_t)15;
-            uintptr_t end = (uintptr_t)(sp + (je + 1) * L);
-            end = end < limit_addr ? end : limit_addr;
-            const int n_units = (int)((end - base + 15) >> 4);
-            const int whole = (int)((limit_addr - base) >> 4);      // units that end at or before the limit
-            const int n_load = n_units < whole ? n_units : whole;
+            // (before the run: only the q callbacks that its first rings reach into)
+            const int jb = it < 0 ? 0 : first_rel + 4 * it;
+            const int je = it < 0 ? first_rel - 1 : (jb + 3 < last_rel ? jb + 3 : last_rel);
+            const unsigned base = (m0 + (unsigned)jb * L2) & ~15u;
+            unsigned end = m0 + (unsigned)(je + 1) * L2;
+            end = end < limit_rel ? end : limit_rel;
+            const unsigned n_units = (end - base + 15) >> 4;
+            const unsigned whole = (limit_rel - base) >> 4;         // units that end at or before the limit
+            const unsigned last_off = 16u * ((n_units < whole ? n_units : whole) - 1);
+            const char *bp = run_ptr + base;
+            // Units past the last one repeat it (nobody reads their copy): loads under a lane predicate
+            // would sit in branches, and the wait for this buffer would then have to be a wait for every
+            // load in flight, the next iteration's included.
 #pragma unroll
             for (int i = 0; i < LOADS; i++) {
-                const int u = lane + 64 * i;
-                d[i] = make_uint4(0, 0, 0, 0);
-                if (u < n_load) d[i] = bd_load_stream16(reinterpret_cast<const uint4 *>(base) + u);
+                const unsigned off = 16u * (unsigned)lane + 1024u * i;
+                d[i] = bd_load_stream16(bp + (off < last_off ? off : last_off));
             }
         } else {
             int64_t jj = j0 + 4 * (int64_t)it + g;
             jj = jj < j_last ? jj : j_last;                     // stand-in rows of the last iteration
-            jj = jj < 0 ? 0 : jj;
+            // before the run: only the q callbacks that its first rings reach into; the rows before them
+            // repeat the first of those (no load sits under a lane predicate: the wait for this buffer
+            // would otherwise have to be a wait for every load in flight)
+            jj = jj < j0 - q_cb ? j0 - q_cb : jj;
             const int16_t *cp = sp + jj * L;
 #pragma unroll
             for (int p = 0; p < PIECES; p++) {
@@ -212,9 +245,17 @@ __global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
                     reinterpret_cast<const bd_u32x4_a2 *>(cp + (p < PL ? 128 * p + 8 * l : off_last)));
                 d[p] = make_uint4(v.x, v.y, v.z, v.w);
             }
+            if (REM) {
+                // the remainder's units in the row's first lanes (they may reach into the next callback,
+                // which exists); the other lanes repeat the last of them
+                const int lr = l < REM_UNITS ? l : REM_UNITS - 1;
+                const bd_u32x4_a2 v = __builtin_nontemporal_load(
+                    reinterpret_cast<const bd_u32x4_a2 *>(cp + 128 * PL + 8 * lr));
+                d[NBUF - 1] = make_uint4(v.x, v.y, v.z, v.w);
+            }
         }
     };
-    auto compute = [&](const uint4 (&d)[PIECES], int it) {
+    auto compute = [&](const auto &d, int it) {
         bd_split_acc x;
         x.a1 = x.b1 = x.a2 = x.b2 = 0.f; x.dc = 0;
         bd_split_acc h_before = x, h_after = x;   // accumulators before / after the pieces of group PSTAR
@@ -262,71 +303,123 @@ __global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
         r.hdc = bd_row_sum(h.dc);
         r.amax = bd_row_max(amax);
         r.pad = 0.f;
+        // (The empty statements keep the sums computed in every lane: moved into the branch of the one
+        // lane that stores them, the last step of each reduction is a lane move plus an add instead
+        // of one add that reads its operand through the lane rotation.)
+        if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1), "v"(r.hre1), "v"(r.him1));
+        if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2), "v"(r.hre2), "v"(r.him2));
+        asm volatile("" :: "v"(r.dc), "v"(r.hdc), "v"(r.amax));
         const int slot = 4 * it + g + 4;   // callback j0 - 4 + slot
         if (l == 0) slots[slot] = r;
+        if (l == lstar) keep[slot][0] = d[PSTAR];     // the piece that straddles the end of the head
     };
-    auto run = [&](const uint4 (&d)[NBUF], int it) {
-        if constexpr (STAGED) {
-            uint4 *stage = lds_stage[wave];
+    // (the scheduling barriers keep the next iteration's loads ahead of this iteration's arithmetic)
+    if constexpr (STAGED) {
+        // One iteration ahead in LDS, two in memory: while the sums of iteration `it` are formed from
+        // pieces in registers, the pieces of it + 1 are on their way from the staged copy and the units
+        // of it + 2 from memory.
+        constexpr int NPC = REM ? PIECES + 1 : PIECES;
+        uint4 *stage = lds_stage[wave];
+        auto put = [&](const uint4 (&d)[NBUF]) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < LOADS; i++) stage[lane + 64 * i] = d[i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int64_t jb = j0 + 4 * (int64_t)it;
-            int64_t jj = jb + g;
-            jj = jj < j_last ? jj : j_last;
+        };
+        struct raw_piece { uint4 v; unsigned e, sh; };    // five dwords from the one below the piece; the shift
+        auto pick = [&](raw_piece (&pc)[NPC], int it) {
+            const int jb = it < 0 ? 0 : first_rel + 4 * it;
+            int jj = first_rel + 4 * it + g;
+            jj = jj < last_rel ? jj : last_rel;
+            jj = jj < jb ? jb : jj;                 // rows before the run that no ring reaches: stand-ins
             // byte offset of the row's first sample inside the staged copy
-            const unsigned row_off = (unsigned)(((uintptr_t)(sp + jb * L) & 15) + (uintptr_t)((jj - jb) * L * 2));
+            const unsigned row_off = ((m0 + (unsigned)jb * L2) & 15) + (unsigned)(jj - jb) * L2;
             const unsigned sh = (row_off & 2) ? 16u : 0u;
             const char *sb = reinterpret_cast<const char *>(stage) + (row_off & ~3u);
-            uint4 pc[PIECES];
 #pragma unroll
-            for (int p = 0; p < PIECES; p++) {
-                const unsigned po = (unsigned)(2 * (p < PL ? 128 * p + 8 * l : off_last));
+            for (int p = 0; p < NPC; p++) {
+                if (p == PIECES && l >= REM_UNITS) break;   // the remainder's units: the row's first lanes
+                const unsigned po = (unsigned)(2 * (p < PL ? 128 * p + 8 * l : (REM ? o_last : off_last)));
                 typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
                 const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(sb + po);
-                const unsigned e = *reinterpret_cast<const unsigned *>(sb + po + 16);
-                pc[p].x = __builtin_amdgcn_alignbit(v.y, v.x, sh);
-                pc[p].y = __builtin_amdgcn_alignbit(v.z, v.y, sh);
-                pc[p].z = __builtin_amdgcn_alignbit(v.w, v.z, sh);
-                pc[p].w = __builtin_amdgcn_alignbit(e, v.w, sh);
+                pc[p].v = make_uint4(v.x, v.y, v.z, v.w);
+                pc[p].e = *reinterpret_cast<const unsigned *>(sb + po + 16);
+            }
+            pc[0].sh = sh;
+        };
+        auto sums = [&](const raw_piece (&raw)[NPC], int it) {
+            const unsigned sh = raw[0].sh;
+            uint4 pc[NPC];
+#pragma unroll
+            for (int p = 0; p < NPC; p++) {
+                pc[p].x = __builtin_amdgcn_alignbit(raw[p].v.y, raw[p].v.x, sh);
+                pc[p].y = __builtin_amdgcn_alignbit(raw[p].v.z, raw[p].v.y, sh);
+                pc[p].z = __builtin_amdgcn_alignbit(raw[p].v.w, raw[p].v.z, sh);
+                pc[p].w = __builtin_amdgcn_alignbit(raw[p].e, raw[p].v.w, sh);
             }
             compute(pc, it);
-        } else {
-            compute(d, it);
+            if (REM && l < REM_UNITS) keep[4 * it + g + 4][1 + l] = pc[NPC - 1];
+        };
+        // P, Q: pieces of the iteration at hand and of the next one, as read from the staged copy
+        raw_piece P[NPC], Q[NPC];
+        auto advance = [&](raw_piece (&next)[NPC], int it) {   // the staged copy moves on to iteration it + 1
+            if (it + 1 < n_it) {
+                put(A);
+                if (it + 2 < n_it) load(A, it + 2);
+                pick(next, it + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int it = it_begin;
+        load(A, it);
+        put(A);
+        if (it + 1 < n_it) load(A, it + 1);
+        pick(P, it);
+        for (;;) {
+            advance(Q, it);
+            sums(P, it);
+            if (++it >= n_it) break;
+            advance(P, it);
+            sums(Q, it);
+            if (++it >= n_it) break;
         }
-    };
-
-    int it = it_begin;
-    load(A, it);
-    for (; it + 2 < n_it; it += 2) {
-        load(B, it + 1);
-        run(A, it);
-        load(A, it + 2);
-        run(B, it + 1);
-    }
-    if (it + 1 < n_it) {
-        load(B, it + 1);
-        run(A, it);
-        run(B, it + 1);
     } else {
-        run(A, it);
+        auto run = [&](const uint4 (&d)[NBUF], int it) {
+            compute(d, it);
+            if (REM && l < REM_UNITS) keep[4 * it + g + 4][1 + l] = d[NBUF - 1];
+        };
+        int it = it_begin;
+        load(A, it);
+        for (; it + 2 < n_it; it += 2) {
+            load(B, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            run(A, it);
+            load(A, it + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            run(B, it + 1);
+        }
+        if (it + 1 < n_it) {
+            load(B, it + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            run(A, it);
+            run(B, it + 1);
+        } else {
+            run(A, it);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- end of the run: slot i holds callback j0 - 4 + i ----
     if (REM) {
-        // the callbacks' remainders, samples 128 PL .. L - 1, from memory (the 16-byte loads may reach up to
-        // seven samples into the next callback, which exists: the stream's last one is not evaluated here)
+        // the callbacks' remainders, samples 128 PL .. L - 1, from the parked units
         for (int sidx = lane + (it_begin < 0 ? 0 : 4); sidx < n_win + 4; sidx += 64) {
-            const int64_t jr = j0 - 4 + sidx;
             bd_split_acc y;
             y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
             float ramax = 0.f;
-            bd_split_partial<NK, BD_SPLIT_REM_MAX / 8>(sp + jr * L + 128 * PL, (int)L - 128 * PL, y, ramax);
+            bd_split_partial<NK, REM_UNITS>(keep[sidx] + 1, (int)L - 128 * PL, y, ramax);
             bd_rot(y.a1, y.b1, 1 * 128 * PL);
             bd_rot(y.a2, y.b2, 2 * 128 * PL);
             bd_split_slot S = slots[sidx];
@@ -354,7 +447,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_split_kernel(bd_split_args a)
             bd_split_acc hh;
             hh.a1 = hh.b1 = hh.a2 = hh.b2 = 0.f; hh.dc = 0;
             float unused = 0.f;
-            bd_split_partial<NK, 1>(sp + jt * L + (c - m), m, hh, unused);
+            bd_split_partial<NK, 1>(keep[i + 4 - q], m, hh, unused);
             // anchored at the piece's first sample, c - m: move to the callback's first sample
             bd_rot(hh.a1, hh.b1, 1 * (c - m));
             bd_rot(hh.a2, hh.b2, 2 * (c - m));
@@ -415,17 +508,18 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     a.head_len = callback_len - a.tail_len;
     a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
     a.divisor = plan.divisor; a.threshold = plan.threshold;
-    dim3 grid;
-    if (!bd_grid_dims((a.n_tasks + 3) / 4, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     // 400 .. 511 samples: two whole callbacks in the ring, the callback ends in group 3; 512 .. 639: one whole
     // callback, the callback ends in group 4.  A remainder (samples past the last whole group) of at most 64
     // samples stays out of the main loop.
     const int pstar = (int)(a.head_len / 128), pl = (int)(callback_len / 128);
     const bool rem = (int)callback_len - 128 * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
     const bool staged = callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE");
+    const unsigned waves = (unsigned)bd_split_waves(staged, rem);
+    dim3 grid;
+    if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
 #define BD_SPLIT_GO(NK, PS, PLAST, RM) do { \
-        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM>), grid, dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM>), grid, dim3(256), 0, st, a); \
+        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM>), grid, dim3(64 * waves), 0, st, a); \
+        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM>), grid, dim3(64 * waves), 0, st, a); \
         launched = true; } while (0)
 #define BD_SPLIT_PICK(NK) do { \
         if (pl == 4 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 4, true); else BD_SPLIT_GO(NK, 0, 4, false); } \

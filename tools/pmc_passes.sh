@@ -16,6 +16,8 @@ PASSES=(
  "TCC_TAG_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum"
  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY"
 )
+# PMC_ONLY="<counters>" runs that one pass instead
+if [ -n "${PMC_ONLY:-}" ]; then PASSES=("$PMC_ONLY"); fi
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
