@@ -200,7 +200,7 @@ class Ctx:
 # --------------------------------------------------------------------------------------------
 # a workload whose samples are resident in HBM
 # --------------------------------------------------------------------------------------------
-def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
+def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values_too=True):
     """Measures one workload; returns (result dict, state kept for the CPU baseline)."""
     import ctypes
     torch, bd, L_ = ctx.torch, ctx.bd, ctx.lib
@@ -235,6 +235,7 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
     ms = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
+    decisions_only = False
     if onset:
         def stage1():  # `values` holds the flux rows, `flags` the band-energy rows
             ctx.check(L_.bd_onset_stft(sr, ctypes.byref(oparams), samples.data_ptr(), streams, n, stride,
@@ -252,9 +253,15 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
                 ctx.check(L_.bd_biquad_envelope(sr, ctypes.byref(bq_params), ctypes.byref(bq_design), samples.data_ptr(),
                                                 streams, n, stride, values.data_ptr(), flags.data_ptr(), out_stride, st))
         else:
-            def stage1():
+            # The reference's strategies return beats only (Strategy::is_beat -> Option<BeatInfo>, src/lib.rs:72-78); the per-callback
+            # detection value is an optional output of this library, kept for parity checks.  The timed
+            # region asks for what the reference produces: decisions and beat lists.  The launch with
+            # values is timed next to it (`kernel_ms_with_values`); BENCH_WITH_VALUES=1 makes it the timed one.
+            decisions_only = not os.environ.get("BENCH_WITH_VALUES")
+
+            def stage1(with_values=not decisions_only):
                 ctx.check(L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
-                                                 values.data_ptr(), flags.data_ptr(), out_stride, st))
+                                                 values.data_ptr() if with_values else None, flags.data_ptr(), out_stride, st))
 
         def stage2():
             ctx.check(L_.bd_refractory(sr, None, L, flags.data_ptr(), out_stride, streams, n_cb, count.data_ptr(),
@@ -281,6 +288,16 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
         print("per-step kernel ms:", [round(e[0].elapsed_time(e[1]), 3) for e in ev], file=sys.stderr)
     k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
     k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+    k1_values_ms = None
+    if decisions_only and with_values_too:
+        # the same launch with the detection values written as well (they feed the parity check below)
+        evv = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(3)]
+        for e in evv:
+            e[0].record()
+            stage1(True)
+            e[1].record()
+        torch.cuda.synchronize()
+        k1_values_ms = sum(e[0].elapsed_time(e[1]) for e in evv) / len(evv)
     kernel_name = launched or {"Spectrum": "bd_spectrum_band_kernel", "LPF": "bd_lpf_window_kernel",
                                "Onset": "bd_stft_flux_kernel", "Biquad": "bd_biquad_env_kernel"}[kind_name]
     total_beats = ctx.sum_over_ranks(int(count.sum().item()))
@@ -289,8 +306,9 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
     world = ctx.world
     value = world * streams * (n / sr) * steps / elapsed
     # algorithmic bytes of one launch of the dominant kernel: every sample that
-    # belongs to a callback read once (2 B) + 5 B written per callback
-    alg_bytes = streams * (n_cb * L * 2 + n_cb * 5)
+    # belongs to a callback read once (2 B) + per callback the decision (1 B) and,
+    # where the launch writes it, the detection value (4 B)
+    alg_bytes = streams * (n_cb * L * 2 + n_cb * (1 if decisions_only else 5))
     if onset:  # every sample of a complete frame once + flux and band energy (8 B) per frame
         alg_bytes = streams * (((n_cb - 1) * L + nfft) * 2 + n_cb * 8) if n_cb else 0
     achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
@@ -319,6 +337,8 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
             "seed": SEED,
             "parallelism": f"stream-sharded x{world}, no collectives",
             "beats_found": total_beats,
+            "outputs": ("decisions + beat lists (what the reference's strategies return); detection values not written"
+                        if decisions_only else "decisions + detection values + beat lists"),
         },
         "roofline": {
             "bound": "hbm",
@@ -334,6 +354,8 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0):
             "refractory_ms": k2_ms,
         },
     }
+    if k1_values_ms is not None:
+        result["roofline"]["kernel_ms_with_values"] = k1_values_ms
     if onset:
         result["roofline"]["note"] = ("this kernel is limited by f32 VALU issue (a 2048-point FFT per 1024 new samples), "
                                       "not by HBM; the HBM fraction is reported for comparison with the other workloads")
@@ -694,7 +716,9 @@ def main() -> None:
         r.pop("workload")
         result, state = r, None
     else:
-        result, state = run_resident(ctx, args.workload, args.steps, args.warmup, args.streams, args.seconds)
+        # (profiling runs pass --no-cpu-baseline: every launch of the dominant kernel is then of the timed kind)
+        result, state = run_resident(ctx, args.workload, args.steps, args.warmup, args.streams, args.seconds,
+                                     with_values_too=not args.no_cpu_baseline)
         if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, state, args.cpu_streams)
 

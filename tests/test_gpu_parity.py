@@ -24,7 +24,12 @@ def _run_gpu(bd, kind, sr, x, L, params=None):
     buf = torch.zeros((n_streams, stride), dtype=torch.int16, device="cuda")
     buf[:, :n] = torch.from_numpy(x).cuda()
     res = bd.analyze_batch(kind, sr, buf, L, n_samples=n, params=params)
+    # decisions only (no value rows): the same decisions and beat lists from every kernel
+    bare = bd.analyze_batch(kind, sr, buf, L, n_samples=n, params=params, want_values=False)
     torch.cuda.synchronize()
+    assert bare.values is None
+    assert torch.equal(bare.flags, res.flags) and torch.equal(bare.beat_count, res.beat_count)
+    assert torch.equal(bare.beat_idx, res.beat_idx) and torch.equal(bare.beat_ms, res.beat_ms)
     return res
 
 
