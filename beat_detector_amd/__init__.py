@@ -30,6 +30,7 @@ from .api import (  # noqa: F401
     batch_candidates,
     batch_max_beats,
     device_count,
+    device_name,
     f32_data_to_i16,
     last_kernel_name,
     lib,
@@ -44,3 +45,4 @@ from .api import (  # noqa: F401
 from .onset import OnsetResult, onset_batch, onset_frames, onset_pick, onset_stft  # noqa: F401,E402
 from .biquad import biquad_beats, biquad_design, biquad_envelope  # noqa: F401,E402
 from .executor import ChunkedExecutor, SynthSource  # noqa: F401,E402
+from . import record  # noqa: F401,E402

@@ -166,6 +166,7 @@ def lib() -> C.CDLL:
         "bd_strerror": (C.c_char_p, [i32]),
         "bd_last_error": (C.c_char_p, []),
         "bd_device_count": (i32, [C.POINTER(i32)]),
+        "bd_device_name": (i32, [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]),
         "bd_kind_count": (i32, []),
         "bd_kind_name": (C.c_char_p, [i32]),
         "bd_kind_description": (C.c_char_p, [i32]),
@@ -225,7 +226,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "bd_default_params bd_strerror bd_last_error bd_device_count bd_kind_count bd_kind_name "
+    "bd_default_params bd_strerror bd_last_error bd_device_count bd_device_name bd_kind_count bd_kind_name "
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_noalloc bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
@@ -247,6 +248,14 @@ def device_count() -> int:
     n = C.c_int(0)
     _check(lib().bd_device_count(C.byref(n)))
     return n.value
+
+
+def device_name(device: int):
+    """(name, total memory in bytes) of GPU `device` (bd_device_name)."""
+    buf = C.create_string_buffer(256)
+    mem = C.c_uint64(0)
+    _check(lib().bd_device_name(int(device), buf, len(buf), C.byref(mem)))
+    return buf.value.decode(), int(mem.value)
 
 
 def last_kernel_name() -> str:

@@ -61,6 +61,20 @@ extern "C" int bd_device_count(int *count)
     return BD_OK;
 }
 
+extern "C" int bd_device_name(int device, char *name, size_t capacity, uint64_t *total_memory_bytes)
+{
+    if (!name || capacity == 0) { bd_set_error("bd_device_name: name buffer missing"); return BD_ERR_INVALID_ARG; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (device < 0 || device >= n) { bd_set_error("bd_device_name: no GPU with index %d", device); return BD_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    const int st = bd_check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+    if (st != BD_OK) return st;
+    snprintf(name, capacity, "%s (%s)", prop.name, prop.gcnArchName);
+    if (total_memory_bytes) *total_memory_bytes = (uint64_t)prop.totalGlobalMem;
+    return BD_OK;
+}
+
 // ---- parameters and plan ----------------------------------------------------------
 extern "C" void bd_default_params(bd_params *p)
 {

@@ -187,3 +187,20 @@ pub fn gpu_count() -> usize {
     unsafe { ffi::bd_device_count(&mut n) };
     n.max(0) as usize
 }
+
+/// Name -> index of every GPU, ordered by name like the reference's
+/// `audio_input_device_list` (`src/record.rs:170-177`) orders its cpal devices.
+pub fn gpu_device_list() -> std::collections::BTreeMap<String, usize> {
+    let mut map = std::collections::BTreeMap::new();
+    for i in 0..gpu_count() {
+        let mut buf = [0 as std::os::raw::c_char; 256];
+        let status = unsafe { ffi::bd_device_name(i as c_int, buf.as_mut_ptr(), buf.len(), std::ptr::null_mut()) };
+        let name = if status == 0 {
+            unsafe { std::ffi::CStr::from_ptr(buf.as_ptr()) }.to_string_lossy().into_owned()
+        } else {
+            format!("Unknown device #{}", i)
+        };
+        map.insert(format!("[{}] {}", i, name), i);
+    }
+    map
+}

@@ -74,6 +74,13 @@ const char *bd_last_error(void);
 /* Number of visible GPUs (0 and BD_OK when there is none). */
 int bd_device_count(int *count);
 
+/* Name and memory of GPU `device`: the analysis-side counterpart of the reference's device listing
+ * helpers (record::audio_input_device_list / print_audio_input_device_configs / get_backends,
+ * src/record.rs:168-198, which enumerate cpal audio devices; audio capture itself stays with the caller).
+ * `name` receives a NUL-terminated string of at most `capacity` bytes (truncated if longer);
+ * `total_memory_bytes` may be NULL.  BD_ERR_NO_DEVICE for an index outside [0, bd_device_count). */
+int bd_device_name(int device, char *name, size_t capacity, uint64_t *total_memory_bytes);
+
 /* ---- StrategyKind metadata ------------------------------------------- */
 /* StrategyKind::values().len(), src/lib.rs:182-184 */
 int bd_kind_count(void);
