@@ -58,7 +58,8 @@ def test_noalloc_matches_analyze_batch_on_consecutive_calls(bd):
     small = torch.zeros((17, (n2 + 7) & ~7), dtype=torch.int16, device=dev)
     bd.synth_fill(small, n_samples=n2, seed=12, first_stream=1000)
     torch.cuda.synchronize()
-    for kind, L in ((bd.StrategyKind.Spectrum, 512), (bd.StrategyKind.LPF, 1024), (bd.StrategyKind.Spectrum, 441)):
+    for kind, L in ((bd.StrategyKind.Spectrum, 512), (bd.StrategyKind.LPF, 1024), (bd.StrategyKind.Spectrum, 441),
+                    (bd.StrategyKind.Spectrum, 529)):
         mb1 = bd.batch_max_beats(kind, SR, n1, L)
         mb2 = bd.batch_max_beats(kind, SR, n2, L)
         want1 = _expect(bd, torch, kind, big, n1, L, mb1)
