@@ -131,6 +131,46 @@ def test_spectrum_split_kernel_callback_lengths(bd, oracle, L):
     np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
+    """Random callback lengths in the split kernel's range, stream counts and lengths (runs of 64
+    callbacks cut anywhere), rows at odd addresses with odd strides, random unpinned choices."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(5):
+        L = int(rng.integers(400, 639))
+        if L % 16 == 0 or L % 63 == 0:
+            L += 1                      # lengths on a granule grid have kernels of their own
+        streams = int(rng.integers(1, 7))
+        n = int(rng.integers(2 * L, 200 * L))
+        kw = {}
+        if rng.integers(0, 2):
+            kw = [dict(spectrum_include_dc=0), dict(spectrum_divisor=2), dict(spectrum_max_hz=50.0),
+                  dict(spectrum_max_hz=10.0), dict(min_amplitude=int(rng.integers(0, 20000)))][int(rng.integers(0, 5))]
+        x = _synth(bd, streams, n, first=int(rng.integers(0, 1000)), seed=int(rng.integers(1, 1 << 30)))
+        if rng.integers(0, 3) == 0:
+            x = rng.integers(-32768, 32768, x.shape).astype(np.int16)        # full-scale noise
+        stride = n + int(rng.integers(0, 9))
+        shift = int(rng.integers(0, 8))
+        flat = torch.zeros(shift + streams * stride, dtype=torch.int16, device="cuda")
+        view = flat[shift:].view(streams, stride)
+        view[:, :n] = torch.from_numpy(x).cuda()
+        bp, op = bd.Params.default(**kw), oracle.default_params(**kw)
+        res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, view, L, n_samples=n, params=bp)
+        assert bd.last_kernel_name() == "bd_spectrum_split_kernel"
+        ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_SPECTRUM, SR, x, L, op)
+        nb, _, _ = oracle.bin_range(SR, op)
+        div = {0: nb, 1: 1024, 2: 0}[op.spectrum_divisor]
+        what = (seed, L, streams, n, stride, shift, kw)
+        assert util.values_close(res.values.cpu().numpy(), ref_v, 32768, div).all(), what
+        adjacent = util.threshold_adjacent(ref_v, op.spectrum_threshold)
+        got_c = res.flags.cpu().numpy()
+        assert ((got_c == ref_c) | adjacent).all(), what
+        if (got_c == ref_c).all():
+            for i in range(streams):
+                assert res.beats(i) == ref_b[i], what
+
+
 @pytest.mark.parametrize("L", [63, 126, 441, 504, 693, 819])
 def test_spectrum_granules_of_63_samples(bd, oracle, L):
     """Callback lengths 63 q up to 819 (441 = 10 ms at 44.1 kHz): granules of 63 samples; short streams,
