@@ -183,9 +183,13 @@ __device__ __forceinline__ float bd_sqrt_rn_normal(float x)
     const float s = __builtin_amdgcn_sqrtf(x);
     const int si = __builtin_bit_cast(int, s);
     const float sd = __builtin_bit_cast(float, si - 1), su = __builtin_bit_cast(float, si + 1);
-    float vd, vu; // x - sd * s, x - su * s (assembly keeps the negation a source modifier of a scalar fma)
-    asm("v_fma_f32 %0, -%2, %4, %5\n\tv_fma_f32 %1, -%3, %4, %5" : "=&v"(vd), "=&v"(vu) : "v"(sd), "v"(su), "v"(s), "v"(x));
-    return __builtin_bit_cast(float, si - 1 + (vd > 0.f ? 1 : 0) + (vu > 0.f ? 1 : 0));
+    // sd * s - x and su * s - x: the exact residuals with their signs turned, so that "residual > 0" is the
+    // sign bit (an exact zero comes out as +0) and the choice is two shifts and adds, no compare / select
+    // (assembly keeps the negation a source modifier of a scalar fma)
+    float nd, nu;
+    asm("v_fma_f32 %0, %2, %4, -%5\n\tv_fma_f32 %1, %3, %4, -%5" : "=&v"(nd), "=&v"(nu) : "v"(sd), "v"(su), "v"(s), "v"(x));
+    const unsigned up = (__builtin_bit_cast(unsigned, nd) >> 31) + (__builtin_bit_cast(unsigned, nu) >> 31);
+    return __builtin_bit_cast(float, si - 1 + (int)up);
 }
 
 // Sum over the wavefront as the butterfly p[l] += p[l ^ o], o = 1, 2, 4, 8, 16, 32,
