@@ -18,34 +18,24 @@ def click_track(n, seed, sr=44100, level=26000, noise=500, period=None, burst_hz
     return np.clip(x, -32768, 32767).astype(np.int16)
 
 
-def value_tolerance(ref_values, max_abs_sample, divisor):
-    """|gpu - ref| <= REL_TOL * |ref| + floor.  The floor (REL_TOL * largest
-    sample / divisor) only matters for bins whose magnitude is below one
-    sample's worth of signal, where both the f32 FFT and the pruned DFT are
-    dominated by rounding; it is five orders of magnitude below the decision
-    threshold."""
-    div = divisor if divisor else 1.0
-    return REL_TOL * np.abs(ref_values) + REL_TOL * max(float(max_abs_sample), 1.0) / div
+def value_tolerance(ref_values, max_abs_sample=None, divisor=None):
+    """|gpu - ref| <= REL_TOL * |ref|: the stated tolerance, with no absolute floor.  (An earlier
+    version added REL_TOL * largest sample / divisor for bins near zero; over the whole GPU suite,
+    1.67 M band values, not one needed it, so it is gone.  The two unused arguments stay for the
+    callers.)"""
+    return REL_TOL * np.abs(np.asarray(ref_values, dtype=np.float64))
 
 
-# How often the absolute floor was what let a value pass (printed at the end of a test session):
-# the relative bound alone is the stated tolerance, the floor only covers bins near zero.
+# Band values compared in a test session (printed at its end).
 FLOOR_STATS = {"values": 0, "needed_floor": 0, "largest_ref_needing_floor": 0.0}
 
 
-def values_close(got, ref_values, max_abs_sample, divisor):
-    """Boolean array: |got - ref| within value_tolerance(); counts the values that pass only
-    through the absolute floor."""
+def values_close(got, ref_values, max_abs_sample=None, divisor=None):
+    """Boolean array: |got - ref| <= REL_TOL * |ref|."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref_values, dtype=np.float64)
-    err = np.abs(got - ref)
-    ok = err <= value_tolerance(ref_values, max_abs_sample, divisor)
-    floor_only = ok & (err > REL_TOL * np.abs(ref))
+    ok = np.abs(got - ref) <= value_tolerance(ref)
     FLOOR_STATS["values"] += int(ok.size)
-    FLOOR_STATS["needed_floor"] += int(floor_only.sum())
-    if floor_only.any():
-        FLOOR_STATS["largest_ref_needing_floor"] = max(FLOOR_STATS["largest_ref_needing_floor"],
-                                                       float(np.abs(ref[floor_only]).max()))
     return ok
 
 
