@@ -386,6 +386,41 @@ def test_refractory_rule_dense_decisions(bd, oracle):
             assert got == want, (sr, L, s)
 
 
+@pytest.mark.parametrize("n_cb", [1, 15, 16, 17, 1023, 1024, 1025, 1039, 2049, 5167])
+def test_refractory_rows_on_16_byte_boundaries_and_any_nonzero_byte(bd, oracle, n_cb):
+    """Rows that start on 16-byte boundaries are read 1024 decisions at a time, the others 64 at a time;
+    a decision is any non-zero byte (0x01, 0x80, 0xff, ...); bytes between n_cb and the row stride are
+    not decisions."""
+    import ctypes as C
+    torch = _torch()
+    rng = np.random.default_rng(n_cb)
+    sr, L = 44100, 512
+    stride = ((n_cb + 15) & ~15) + 16
+    host = rng.integers(1, 256, (6, stride)).astype(np.uint8)        # garbage past n_cb
+    dens = [1.0, 0.0, 0.5, 0.05, 0.01, 0.2]
+    for s in range(6):
+        host[s, :n_cb] = np.where(rng.random(n_cb) < dens[s], rng.choice([1, 2, 0x80, 0xff], n_cb), 0)
+    for shift in (0, 3):                      # rows on and off 16-byte boundaries
+        flat = torch.zeros(shift + host.size + 16, dtype=torch.uint8, device="cuda")
+        view = flat[shift:shift + host.size].view(6, stride)
+        view.copy_(torch.from_numpy(host).cuda())
+        count, idx, ms = bd.refractory(sr, L, view[:, :n_cb], max_beats=n_cb)
+        torch.cuda.synchronize()
+        count, idx, ms = count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()
+        Lo = oracle.lib()
+        for s in range(6):
+            st = oracle.State()
+            Lo.bdo_state_new(C.byref(st), sr)
+            want = []
+            for j in range(n_cb):
+                Lo.bdo_state_update_time(C.byref(st), L)
+                if Lo.bdo_last_beat_beyond_threshold(C.byref(st), 400) and host[s, j]:
+                    Lo.bdo_state_mark_beat(C.byref(st))
+                    want.append((j, st.beat_time_ms))
+            got = list(zip(idx[s, :count[s]].tolist(), ms[s, :count[s]].tolist()))
+            assert got == want, (n_cb, shift, s)
+
+
 def test_beat_list_capacity_is_reported_not_overrun(bd):
     torch = _torch()
     flags = torch.ones((3, 500), dtype=torch.uint8, device="cuda")
