@@ -472,10 +472,19 @@ __global__ __launch_bounds__(256) void bd_spectrum_window_kernel(bd_win_args a)
             for (int q = 0; q < 8; q++)
                 bd_win_absmax(amax, 2 * q >= t_own ? x[2 * q] : 0.f, 2 * q + 1 >= t_own ? x[2 * q + 1] : 0.f);
         }
-        if (L > BD_RING_LEN) { // the part of a longer callback that lies before the ring
+        if (L > BD_RING_LEN) {
+            // The part of a longer callback that lies before the ring, 512 samples per step (16 bytes per
+            // lane).  A step that starts before the ring may reach up to 511 samples into it: those belong
+            // to the callback as well, so nothing needs masking.
             const int64_t end = (int64_t)((j0 + i + 1) * L);
-            for (int64_t idx = end - (int64_t)L + lane; idx < end - BD_RING_LEN; idx += 64)
-                amax = fmaxf(amax, fabsf((float)sp[idx]));
+            const int64_t head_end = end - BD_RING_LEN;
+            for (int64_t c = end - (int64_t)L; c < head_end; c += 512) {
+                const bd_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a2 *>(sp + c + 8 * lane));
+                const unsigned hw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    bd_win_absmax(amax, (float)(short)(hw[q] & 0xffff), (float)(short)((int)hw[q] >> 16));
+            }
         }
         const bool gate = __builtin_amdgcn_ballot_w64(fminf(amax, 32767.f) >= (float)a.min_amp) != 0;
         gate_mask |= gate ? (1ull << i) : 0ull;
