@@ -16,63 +16,73 @@ static const int16_t *bd_click_host()
     return click;
 }
 
+#define BD_SYNTH_ROUNDS 16 /* groups of 8 samples per thread: the per-stream set-up is paid once for all of them */
+
 __global__ __launch_bounds__(256) void bd_synth_kernel(int16_t *samples, uint64_t n_streams,
                                                        uint64_t n_samples, uint64_t stride,
                                                        uint64_t first_stream, uint64_t seed,
-                                                       uint32_t sampling_rate, uint64_t groups_per_stream)
+                                                       uint32_t sampling_rate, uint64_t groups_per_stream,
+                                                       uint64_t threads_per_stream)
 {
-    // one thread per group of 8 consecutive samples
+    // A thread writes the groups j, j + T, j + 2 T, ... of 8 consecutive samples of one stream (T =
+    // threads per stream): consecutive threads write consecutive 16-byte units in every round, and the
+    // stream's parameters (three 64-bit hashes, three divisions) are derived once per thread.
     const uint64_t t = bd_block_index() * blockDim.x + threadIdx.x;
-    if (t >= n_streams * groups_per_stream) return;
-    const uint64_t s = t / groups_per_stream;
-    const uint64_t n0 = (t - s * groups_per_stream) * 8;
+    if (t >= n_streams * threads_per_stream) return;
+    const uint64_t s = t / threads_per_stream;
+    const uint64_t j = t - s * threads_per_stream;
     const bd_synth_stream p = bd_synth_stream_params(seed, first_stream + s, sampling_rate);
-    // bd_synth_sample() for n0 .. n0 + 7 with the position inside the click pattern carried from
-    // sample to sample (one division per thread instead of one per sample); same bits
-    int16_t v[8];
-    uint64_t ci = 0;
-    uint32_t phase = 0, level = 0;
-    bool level_known = false;
-    // samples before `skip` precede the first click (8: the whole group does)
-    const int skip = n0 >= p.offset ? 0 : (p.offset - n0 < 8 ? (int)(p.offset - n0) : 8);
-    if (skip < 8) {
-        const uint64_t rel = n0 + (uint64_t)skip - p.offset;
-        ci = rel >> 32 ? rel / p.period : (uint64_t)((uint32_t)rel / p.period);
-        phase = (uint32_t)(rel - ci * p.period);
-    }
-    // the noise hash takes n in 32-bit halves; the high half is constant inside a group of 8
-    uint32_t hk = p.key + (uint32_t)n0 * 0x9E3779B1u + (uint32_t)(n0 >> 32);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t h = bd_mix32(hk);
-        hk += 0x9E3779B1u;
-        int32_t x = (int32_t)(((h >> 16) * 1001u) >> 16) - 500;
-        if (i >= skip) {
-            if (phase < BD_CLICK_LEN) {
-                if (!level_known) {
-                    const uint32_t jitter = 768u + bd_mix32(p.click_key ^ (uint32_t)ci) % 257u;
-                    level = (uint32_t)(((int64_t)p.level_q15 * jitter) >> 10);
-                    level_known = true;
-                }
-                x += (int32_t)(((int64_t)bd_click_dev[phase] * (int64_t)level) >> 15);
-            }
-            if (++phase == p.period) { phase = 0; ci++; level_known = false; }
+    for (int r = 0; r < BD_SYNTH_ROUNDS; r++) {
+        const uint64_t g = j + (uint64_t)r * threads_per_stream;
+        if (g >= groups_per_stream) break;
+        const uint64_t n0 = g * 8;
+        // bd_synth_sample() for n0 .. n0 + 7 with the position inside the click pattern carried from
+        // sample to sample (one division per group instead of one per sample); same bits
+        int16_t v[8];
+        uint64_t ci = 0;
+        uint32_t phase = 0, level = 0;
+        bool level_known = false;
+        // samples before `skip` precede the first click (8: the whole group does)
+        const int skip = n0 >= p.offset ? 0 : (p.offset - n0 < 8 ? (int)(p.offset - n0) : 8);
+        if (skip < 8) {
+            const uint64_t rel = n0 + (uint64_t)skip - p.offset;
+            ci = rel >> 32 ? rel / p.period : (uint64_t)((uint32_t)rel / p.period);
+            phase = (uint32_t)(rel - ci * p.period);
         }
-        x = x > 32767 ? 32767 : x;
-        x = x < -32768 ? -32768 : x;
-        v[i] = (int16_t)x;
-    }
-    int16_t *dst = samples + s * stride + n0;
-    if (n0 + 8 <= n_samples && ((uintptr_t)dst % 16 == 0)) {
-        uint4 pk;
-        pk.x = (uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
-        pk.y = (uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
-        pk.z = (uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
-        pk.w = (uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
-        *reinterpret_cast<uint4 *>(dst) = pk;
-    } else {
-        for (int i = 0; i < 8; i++)
-            if (n0 + i < n_samples) dst[i] = v[i];
+        // the noise hash takes n in 32-bit halves; the high half is constant inside a group of 8
+        uint32_t hk = p.key + (uint32_t)n0 * 0x9E3779B1u + (uint32_t)(n0 >> 32);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t h = bd_mix32(hk);
+            hk += 0x9E3779B1u;
+            int32_t x = (int32_t)(((h >> 16) * 1001u) >> 16) - 500;
+            if (i >= skip) {
+                if (phase < BD_CLICK_LEN) {
+                    if (!level_known) {
+                        const uint32_t jitter = 768u + bd_mix32(p.click_key ^ (uint32_t)ci) % 257u;
+                        level = (uint32_t)(((int64_t)p.level_q15 * jitter) >> 10);
+                        level_known = true;
+                    }
+                    x += (int32_t)(((int64_t)bd_click_dev[phase] * (int64_t)level) >> 15);
+                }
+                if (++phase == p.period) { phase = 0; ci++; level_known = false; }
+            }
+            x = x > 32767 ? 32767 : x;
+            x = x < -32768 ? -32768 : x;
+            v[i] = (int16_t)x;
+        }
+        int16_t *dst = samples + s * stride + n0;
+        if (n0 + 8 <= n_samples && ((uintptr_t)dst % 16 == 0)) {
+            uint4 pk;
+            pk.x = (uint16_t)v[0] | ((uint32_t)(uint16_t)v[1] << 16);
+            pk.y = (uint16_t)v[2] | ((uint32_t)(uint16_t)v[3] << 16);
+            pk.z = (uint16_t)v[4] | ((uint32_t)(uint16_t)v[5] << 16);
+            pk.w = (uint16_t)v[6] | ((uint32_t)(uint16_t)v[7] << 16);
+            *reinterpret_cast<uint4 *>(dst) = pk;
+        } else {
+            for (int i = 0; i < 8; i++)
+                if (n0 + i < n_samples) dst[i] = v[i];
+        }
     }
 }
 
@@ -101,12 +111,13 @@ extern "C" int bd_synth_fill(int16_t *samples, uint64_t n_streams, uint64_t n_sa
         }
     }
     const uint64_t groups = (n_samples + 7) / 8;
-    const uint64_t grid64 = (n_streams * groups + 255) / 256;
+    const uint64_t threads_per_stream = (groups + BD_SYNTH_ROUNDS - 1) / BD_SYNTH_ROUNDS;
+    const uint64_t grid64 = (n_streams * threads_per_stream + 255) / 256;
     dim3 grid_dims;
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("bd_synth_fill: batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(bd_synth_kernel, grid_dims, dim3(256), 0, st,
                        samples, n_streams, n_samples, stream_stride, first_stream, seed,
-                       sampling_rate, groups);
+                       sampling_rate, groups, threads_per_stream);
     return bd_check_hip(hipGetLastError(), "launch bd_synth_kernel");
 }
 
