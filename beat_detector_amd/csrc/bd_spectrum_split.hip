@@ -1,4 +1,4 @@
-// Spectrum strategy, batched, for callback lengths of 257 .. 639 samples that sit on no
+// Spectrum strategy, batched, for callback lengths of 257 .. 767 samples that sit on no
 // grid (the reference's author reports "mostly 500-540" samples per callback on Linux,
 // src/strategies/spectrum.rs:40-42; 1024 elsewhere).
 //
@@ -18,9 +18,9 @@
 // evaluates each ring on its own).  Callbacks before the stream contribute zeros (spectrum.rs:50-51).
 //
 // A row of 16 lanes owns one callback per iteration (four callbacks per wavefront and
-// iteration); lane l holds the samples 128 p + 8 l + m of it (p < 5, m < 8), so every load
+// iteration); lane l holds the samples 128 p + 8 l + m of it (p < 6, m < 8), so every load
 // instruction covers 256 contiguous bytes per row (16-byte loads at 2-byte-aligned addresses),
-// 640 samples in all.  Twiddles are compile-time constants w^{k (128 p + m)} times one rotation by the
+// 768 samples in all.  Twiddles are compile-time constants w^{k (128 p + m)} times one rotation by the
 // lane's w^{8 k l}; DPP row reductions.  Samples of a lane that lie past the callback are removed
 // by per-lane masks computed once.  The head is a prefix of the callback: the accumulators as they
 // stand after the pieces that lie entirely inside it (a compile-time piece index, a lane
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
 {
     constexpr int WAVES = bd_split_waves(STAGED, REM);
     constexpr int PIECES = REM ? PL : PL + 1;
-    constexpr int LOADS = PL == 4 ? 6 : (PL == 3 ? 5 : 4);   // 64 x LOADS units of 16 bytes hold four callbacks
+    constexpr int LOADS = PL == 5 ? 7 : (PL == 4 ? 6 : (PL == 3 ? 5 : 4));   // 64 x LOADS units of 16 bytes hold four callbacks
     constexpr int REM_UNITS = BD_SPLIT_REM_MAX / 8;
     constexpr int NBUF = STAGED ? LOADS : (REM ? PIECES + 1 : PIECES);
     constexpr int KEEP = REM ? 1 + REM_UNITS : 1;     // parked per callback: the head's last piece, the remainder
@@ -482,9 +482,9 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
 
 bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
 {
-    // bins 0 .. 2, no Nyquist packing; lengths that a row of 16 lanes x 24 .. 40 samples covers with most
+    // bins 0 .. 2, no Nyquist packing; lengths that a row of 16 lanes x 24 .. 48 samples covers with most
     // lanes busy and whose ring spans at most four callbacks (three whole ones and a tail)
-    if (callback_len <= 256 || callback_len >= 640) return false;
+    if (callback_len <= 256 || callback_len >= 768) return false;
     return plan.last_bin <= 2 && !(plan.dc_packs_nyquist && plan.first_bin == 0);
 }
 
@@ -508,8 +508,8 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     a.head_len = callback_len - a.tail_len;
     a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
     a.divisor = plan.divisor; a.threshold = plan.threshold;
-    // 257 .. 341 samples: three whole callbacks in the ring; 342 .. 511: two; 512 .. 639: one.  The callback
-    // ends in group 2 (257 .. 383), 3 (385 .. 511) or 4.  A remainder (samples past the last whole group)
+    // 257 .. 341 samples: three whole callbacks in the ring; 342 .. 511: two; 512 .. 767: one.  The callback
+    // ends in group 2 (257 .. 383), 3 (385 .. 511), 4 (513 .. 639) or 5.  A remainder (samples past the last whole group)
     // of at most BD_SPLIT_REM_MAX samples stays out of the main loop.
     const int pstar = (int)(a.head_len / 128), pl = (int)(callback_len / 128);
     const bool rem = (int)callback_len - 128 * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
@@ -529,7 +529,9 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
         else if (pl == 3 && pstar == 3) { BD_SPLIT_GO(NK, 3, 3, false); } \
         else if (pl == 2 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 2, true); else BD_SPLIT_GO(NK, 0, 2, false); } \
         else if (pl == 2 && pstar == 1) { BD_SPLIT_GO(NK, 1, 2, false); } \
-        else if (pl == 2 && pstar == 2) { BD_SPLIT_GO(NK, 2, 2, false); } } while (0)
+        else if (pl == 2 && pstar == 2) { BD_SPLIT_GO(NK, 2, 2, false); } \
+        else if (pl == 5 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 5, true); else BD_SPLIT_GO(NK, 2, 5, false); } \
+        else if (pl == 5 && pstar == 3) { BD_SPLIT_GO(NK, 3, 5, false); } } while (0)
     bool launched = false;
     if (plan.last_bin == 0) BD_SPLIT_PICK(0);
     else if (plan.last_bin == 1) BD_SPLIT_PICK(1);
