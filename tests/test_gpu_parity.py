@@ -244,7 +244,7 @@ def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
 @pytest.mark.parametrize("sr", [8000, 16000, 22050, 48000, 96000, 192000])
 def test_spectrum_other_sampling_rates(bd, oracle, sr):
     x = _synth(bd, 2, 60000, first=5, sr=sr)
-    for L in (512, 1024, 600):
+    for L in (512, 1024, 600, 529, 300, 700, 270):      # the last five: every flavour of the split kernel above 32 kHz
         _compare(bd, oracle, "Spectrum", sr, x, L)
 
 
