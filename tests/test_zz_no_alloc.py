@@ -110,3 +110,33 @@ def test_noalloc_rejects_what_does_not_fit_and_bad_arguments(bd):
     assert L_.bd_analyze_batch_noalloc(0, SR, None, x.data_ptr(), 4, 100, 4096, 512, count.data_ptr(), None, None, 0, None) == 0
     torch.cuda.synchronize()
     assert (count.cpu().numpy() == 0).all()
+
+
+def test_noalloc_inside_a_captured_graph(bd):
+    """What the entry point is for: captured into a HIP graph (no allocation may happen there) and
+    replayed on new samples in the same buffers."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, L = SR * 9, 529
+    kind = bd.StrategyKind.Spectrum
+    mb = bd.batch_max_beats(kind, SR, n, L)
+    x = torch.zeros((21, (n + 63) & ~63), dtype=torch.int16, device=dev)
+    count = torch.zeros((21,), dtype=torch.int32, device=dev)
+    idx = torch.zeros((21, mb), dtype=torch.int32, device=dev)
+    ms = torch.zeros((21, mb), dtype=torch.int32, device=dev)
+    bd.synth_fill(x, n_samples=n, seed=21)
+    _raw_call(bd, torch, kind, x, n, L, mb)             # first call on the device happens outside the capture
+    side = torch.cuda.Stream(device=dev)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = bd.lib().bd_analyze_batch_noalloc(kind.value, SR, None, x.data_ptr(), 21, n, x.shape[1], L, count.data_ptr(),
+                                               idx.data_ptr(), ms.data_ptr(), mb, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, bd.lib().bd_last_error().decode()
+    for seed in (21, 22, 23):
+        bd.synth_fill(x, n_samples=n, seed=seed)
+        count.fill_(-7); idx.fill_(-7); ms.fill_(-7)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = _expect(bd, torch, kind, x, n, L, mb)
+        _same((count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()), want, mb)
