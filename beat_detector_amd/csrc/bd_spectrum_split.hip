@@ -1,4 +1,4 @@
-// Spectrum strategy, batched, for callback lengths of 257 .. 767 samples that sit on no
+// Spectrum strategy, batched, for callback lengths of 129 .. 767 samples that sit on no
 // grid (the reference's author reports "mostly 500-540" samples per callback on Linux,
 // src/strategies/spectrum.rs:40-42; 1024 elsewhere).
 //
@@ -135,8 +135,43 @@ __device__ __forceinline__ void bd_split_partial(const uint4 *units, int m, bd_s
     }
 }
 
-// PSTAR: index of the 128-sample group that holds the end of the head (head_len / 128).
-// PL: index of the group that holds the end of the callback (callback_len / 128): the groups
+// Twiddles of sample GROUP p + m of a callback (without the lane's offset 8 l), entry 8 p + m.
+template <int LPC> struct bd_split_tw;
+template <> struct bd_split_tw<16> {
+    static __device__ __forceinline__ constexpr float C(int k, int i) { return BD_SP_C[k][i]; }
+    static __device__ __forceinline__ constexpr float S(int k, int i) { return BD_SP_S[k][i]; }
+};
+template <> struct bd_split_tw<8> {
+    static __device__ __forceinline__ constexpr float C(int k, int i) { return BD_SP8_C[k][i]; }
+    static __device__ __forceinline__ constexpr float S(int k, int i) { return BD_SP8_S[k][i]; }
+};
+
+// Sum / maximum over the LPC lanes of a callback, valid in all of them.  Groups of 8 lanes: partners
+// l ^ 1, l ^ 2, then the mirror inside the half-row (the other quad's sum).
+template <int LPC> __device__ __forceinline__ float bd_group_sum(float v)
+{
+    if constexpr (LPC == 16) return bd_row_sum(v);
+    v += bd_dpp_f<0xB1>(v); v += bd_dpp_f<0x4E>(v); v += bd_dpp_f<0x141>(v);
+    return v;
+}
+template <int LPC> __device__ __forceinline__ int bd_group_sum(int v)
+{
+    if constexpr (LPC == 16) return bd_row_sum(v);
+    v += bd_dpp_i<0xB1>(v); v += bd_dpp_i<0x4E>(v); v += bd_dpp_i<0x141>(v);
+    return v;
+}
+template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
+{
+    if constexpr (LPC == 16) {
+        return bd_row_max(v);
+    } else {
+        v = fmaxf(v, bd_dpp_f<0xB1>(v)); v = fmaxf(v, bd_dpp_f<0x4E>(v)); v = fmaxf(v, bd_dpp_f<0x141>(v));
+        return v;
+    }
+}
+
+// PSTAR: index of the group of GROUP samples that holds the end of the head (head_len / GROUP).
+// PL: index of the group that holds the end of the callback (callback_len / GROUP): the groups
 // before it are whole in every lane, the groups after it are not read at all.
 // REM: the samples of group PL (the callback's remainder, at most BD_SPLIT_REM_MAX) stay out of
 // the main loop, which then has no masks and one piece less per lane: the first lanes of a row park
@@ -148,22 +183,28 @@ __device__ __forceinline__ void bd_split_partial(const uint4 *units, int m, bd_s
 // iteration's four callbacks to LDS as they lie in memory (aligned, contiguous 16-byte units),
 // and the lanes pick their pieces from there: a 16-byte LDS read at the dword below the piece,
 // one more dword, and a funnel shift by 16 bits in the rows that start on an odd sample.
-template <int NK, int PSTAR, int PL, bool STAGED, bool REM>
+// LPC: lanes per callback.  16 (groups of 128 samples, four callbacks per iteration) for callbacks of 385
+// samples and more; 8 (groups of 64 samples, eight callbacks per iteration) for 129 .. 383 samples, whose
+// ring spans up to seven whole callbacks.
+template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16>
 __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_split_kernel(bd_split_args a)
 {
     constexpr int WAVES = bd_split_waves(STAGED, REM);
+    constexpr int GROUP = 8 * LPC;                    // samples of a callback that one load instruction covers
+    constexpr int ROWS = 64 / LPC;                    // callbacks per iteration
     constexpr int PIECES = REM ? PL : PL + 1;
-    constexpr int LOADS = PL == 5 ? 7 : (PL == 4 ? 6 : (PL == 3 ? 5 : 4));   // 64 x LOADS units of 16 bytes hold four callbacks
+    // 64 x LOADS units of 16 bytes hold ROWS callbacks of up to GROUP (PL + 1) - 1 samples from any 2-byte offset
+    constexpr int LOADS = ((ROWS * (GROUP * (PL + 1) - 1) * 2 + 15 + 15) / 16 + 1 + 63) / 64;
     constexpr int REM_UNITS = BD_SPLIT_REM_MAX / 8;
     constexpr int NBUF = STAGED ? LOADS : (REM ? PIECES + 1 : PIECES);
     constexpr int KEEP = REM ? 1 + REM_UNITS : 1;     // parked per callback: the head's last piece, the remainder
     static_assert(PSTAR < PIECES, "the head ends inside a group of the main loop");
-    __shared__ bd_split_slot lds_slots[WAVES][BD_SPLIT_RUN + 4];
-    __shared__ __attribute__((aligned(16))) uint4 lds_keep[WAVES][BD_SPLIT_RUN + 4][KEEP];
+    __shared__ bd_split_slot lds_slots[WAVES][BD_SPLIT_RUN + ROWS];
+    __shared__ __attribute__((aligned(16))) uint4 lds_keep[WAVES][BD_SPLIT_RUN + ROWS][KEEP];
     __shared__ __attribute__((aligned(16))) uint4 lds_stage[STAGED ? WAVES : 1][STAGED ? 64 * LOADS + 2 : 1];
 
     const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, l = lane & 15;
+    const int g = lane / LPC, l = lane % LPC;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t task = bd_block_index() * WAVES + wave;
     if (task >= a.n_tasks) return;
@@ -171,8 +212,8 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int64_t j0 = (int64_t)(task - s * a.runs_per_stream) * BD_SPLIT_RUN;
     const int64_t left = (int64_t)a.n_cb - j0;
     const int n_win = left < BD_SPLIT_RUN ? (int)left : BD_SPLIT_RUN;
-    const int n_it = (n_win + 3) / 4;
-    const int it_begin = j0 > 0 ? -1 : 0;   // the q callbacks before the run (q <= 4); none before the stream
+    const int n_it = (n_win + ROWS - 1) / ROWS;
+    const int it_begin = j0 > 0 ? -1 : 0;   // the q callbacks before the run (q <= ROWS); none before the stream
     const int16_t *sp = a.samples + s * a.stride;
     const int64_t L = a.callback_len;
     bd_split_slot *slots = lds_slots[wave];
@@ -180,8 +221,8 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int q_cb = (int)a.q;
 
     // ---- what a lane's place inside its callback fixes, once ----
-    unsigned mask[4];    // dword d of the masked piece holds samples 128 PL + 8 l + 2 d, + 1
-    const int o_last = 128 * PL + 8 * l;
+    unsigned mask[4];    // dword d of the masked piece holds samples GROUP PL + 8 l + 2 d, + 1
+    const int o_last = GROUP * PL + 8 * l;
     // a masked piece that lies past the callback reads the lane's first piece instead
     const int off_last = o_last < (int)L ? o_last : 8 * l;
 #pragma unroll
@@ -191,7 +232,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
     // the head ends inside group PSTAR: there the lanes below `lstar` lie entirely inside it
     const int c = (int)a.head_len;
-    const int lstar = (c - 128 * PSTAR) >> 3;
+    const int lstar = (c - GROUP * PSTAR) >> 3;
     const bool below = l < lstar;
 
     const int64_t j_last = j0 + n_win - 1;
@@ -211,11 +252,11 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     uint4 B[STAGED ? 1 : NBUF];
     auto load = [&](uint4 (&d)[NBUF], int it) {
         if (STAGED) {
-            // callbacks jb .. jb + 3 (those up to j_last) as 16-byte units from the unit that holds
+            // callbacks jb .. jb + ROWS - 1 (those up to j_last) as 16-byte units from the unit that holds
             // the first sample of callback jb
             // (before the run: only the q callbacks that its first rings reach into)
-            const int jb = it < 0 ? 0 : first_rel + 4 * it;
-            const int je = it < 0 ? first_rel - 1 : (jb + 3 < last_rel ? jb + 3 : last_rel);
+            const int jb = it < 0 ? 0 : first_rel + ROWS * it;
+            const int je = it < 0 ? first_rel - 1 : (jb + ROWS - 1 < last_rel ? jb + ROWS - 1 : last_rel);
             const unsigned base = (m0 + (unsigned)jb * L2) & ~15u;
             unsigned end = m0 + (unsigned)(je + 1) * L2;
             end = end < limit_rel ? end : limit_rel;
@@ -232,7 +273,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 d[i] = bd_load_stream16(bp + (off < last_off ? off : last_off));
             }
         } else {
-            int64_t jj = j0 + 4 * (int64_t)it + g;
+            int64_t jj = j0 + ROWS * (int64_t)it + g;
             jj = jj < j_last ? jj : j_last;                     // stand-in rows of the last iteration
             // before the run: only the q callbacks that its first rings reach into; the rows before them
             // repeat the first of those (no load sits under a lane predicate: the wait for this buffer
@@ -242,7 +283,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
 #pragma unroll
             for (int p = 0; p < PIECES; p++) {
                 const bd_u32x4_a2 v = __builtin_nontemporal_load(
-                    reinterpret_cast<const bd_u32x4_a2 *>(cp + (p < PL ? 128 * p + 8 * l : off_last)));
+                    reinterpret_cast<const bd_u32x4_a2 *>(cp + (p < PL ? GROUP * p + 8 * l : off_last)));
                 d[p] = make_uint4(v.x, v.y, v.z, v.w);
             }
             if (REM) {
@@ -250,11 +291,12 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 // which exists); the other lanes repeat the last of them
                 const int lr = l < REM_UNITS ? l : REM_UNITS - 1;
                 const bd_u32x4_a2 v = __builtin_nontemporal_load(
-                    reinterpret_cast<const bd_u32x4_a2 *>(cp + 128 * PL + 8 * lr));
+                    reinterpret_cast<const bd_u32x4_a2 *>(cp + GROUP * PL + 8 * lr));
                 d[NBUF - 1] = make_uint4(v.x, v.y, v.z, v.w);
             }
         }
     };
+    using TW = bd_split_tw<LPC>;
     auto compute = [&](const auto &d, int it) {
         bd_split_acc x;
         x.a1 = x.b1 = x.a2 = x.b2 = 0.f; x.dc = 0;
@@ -269,16 +311,16 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 const int v = (int)(p < PL ? w[qq] : (w[qq] & mask[qq]));
                 const float x0 = (float)(short)(v & 0xffff);
                 const float x1 = (float)(short)(v >> 16);
-                const int i0 = 8 * p + 2 * qq, i1 = i0 + 1;
+                const int i0 = 8 * p + 2 * qq, i1 = i0 + 1;   // table entry of sample GROUP p + 2 qq (+ 1)
                 x.dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, x.dc, false);
                 amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
                 if (NK >= 1) {
-                    x.a1 = __builtin_fmaf(x0, BD_SP_C[0][i0], x.a1); x.b1 = __builtin_fmaf(x0, BD_SP_S[0][i0], x.b1);
-                    x.a1 = __builtin_fmaf(x1, BD_SP_C[0][i1], x.a1); x.b1 = __builtin_fmaf(x1, BD_SP_S[0][i1], x.b1);
+                    x.a1 = __builtin_fmaf(x0, TW::C(0, i0), x.a1); x.b1 = __builtin_fmaf(x0, TW::S(0, i0), x.b1);
+                    x.a1 = __builtin_fmaf(x1, TW::C(0, i1), x.a1); x.b1 = __builtin_fmaf(x1, TW::S(0, i1), x.b1);
                 }
                 if (NK >= 2) {
-                    x.a2 = __builtin_fmaf(x0, BD_SP_C[1][i0], x.a2); x.b2 = __builtin_fmaf(x0, BD_SP_S[1][i0], x.b2);
-                    x.a2 = __builtin_fmaf(x1, BD_SP_C[1][i1], x.a2); x.b2 = __builtin_fmaf(x1, BD_SP_S[1][i1], x.b2);
+                    x.a2 = __builtin_fmaf(x0, TW::C(1, i0), x.a2); x.b2 = __builtin_fmaf(x0, TW::S(1, i0), x.b2);
+                    x.a2 = __builtin_fmaf(x1, TW::C(1, i1), x.a2); x.b2 = __builtin_fmaf(x1, TW::S(1, i1), x.b2);
                 }
             }
             if (p == PSTAR) h_after = x;
@@ -292,16 +334,16 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         bd_split_slot r;
         r.re1 = r.im1 = r.re2 = r.im2 = r.hre1 = r.him1 = r.hre2 = r.him2 = 0.f;
         if (NK >= 1) {
-            r.re1 = bd_row_sum(x.a1 * lc1 - x.b1 * ls1); r.im1 = bd_row_sum(x.a1 * ls1 + x.b1 * lc1);
-            r.hre1 = bd_row_sum(h.a1 * lc1 - h.b1 * ls1); r.him1 = bd_row_sum(h.a1 * ls1 + h.b1 * lc1);
+            r.re1 = bd_group_sum<LPC>(x.a1 * lc1 - x.b1 * ls1); r.im1 = bd_group_sum<LPC>(x.a1 * ls1 + x.b1 * lc1);
+            r.hre1 = bd_group_sum<LPC>(h.a1 * lc1 - h.b1 * ls1); r.him1 = bd_group_sum<LPC>(h.a1 * ls1 + h.b1 * lc1);
         }
         if (NK >= 2) {
-            r.re2 = bd_row_sum(x.a2 * lc2 - x.b2 * ls2); r.im2 = bd_row_sum(x.a2 * ls2 + x.b2 * lc2);
-            r.hre2 = bd_row_sum(h.a2 * lc2 - h.b2 * ls2); r.him2 = bd_row_sum(h.a2 * ls2 + h.b2 * lc2);
+            r.re2 = bd_group_sum<LPC>(x.a2 * lc2 - x.b2 * ls2); r.im2 = bd_group_sum<LPC>(x.a2 * ls2 + x.b2 * lc2);
+            r.hre2 = bd_group_sum<LPC>(h.a2 * lc2 - h.b2 * ls2); r.him2 = bd_group_sum<LPC>(h.a2 * ls2 + h.b2 * lc2);
         }
-        r.dc = bd_row_sum(x.dc);
-        r.hdc = bd_row_sum(h.dc);
-        r.amax = bd_row_max(amax);
+        r.dc = bd_group_sum<LPC>(x.dc);
+        r.hdc = bd_group_sum<LPC>(h.dc);
+        r.amax = bd_group_max<LPC>(amax);
         r.pad = 0.f;
         // (The empty statements keep the sums computed in every lane: moved into the branch of the one
         // lane that stores them, the last step of each reduction is a lane move plus an add instead
@@ -309,7 +351,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1), "v"(r.hre1), "v"(r.him1));
         if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2), "v"(r.hre2), "v"(r.him2));
         asm volatile("" :: "v"(r.dc), "v"(r.hdc), "v"(r.amax));
-        const int slot = 4 * it + g + 4;   // callback j0 - 4 + slot
+        const int slot = ROWS * it + g + ROWS;   // callback j0 - ROWS + slot
         if (l == 0) slots[slot] = r;
         if (l == lstar) keep[slot][0] = d[PSTAR];     // the piece that straddles the end of the head
     };
@@ -330,8 +372,8 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         };
         struct raw_piece { uint4 v; unsigned e, sh; };    // five dwords from the one below the piece; the shift
         auto pick = [&](raw_piece (&pc)[NPC], int it) {
-            const int jb = it < 0 ? 0 : first_rel + 4 * it;
-            int jj = first_rel + 4 * it + g;
+            const int jb = it < 0 ? 0 : first_rel + ROWS * it;
+            int jj = first_rel + ROWS * it + g;
             jj = jj < last_rel ? jj : last_rel;
             jj = jj < jb ? jb : jj;                 // rows before the run that no ring reaches: stand-ins
             // byte offset of the row's first sample inside the staged copy
@@ -341,7 +383,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
 #pragma unroll
             for (int p = 0; p < NPC; p++) {
                 if (p == PIECES && l >= REM_UNITS) break;   // the remainder's units: the row's first lanes
-                const unsigned po = (unsigned)(2 * (p < PL ? 128 * p + 8 * l : (REM ? o_last : off_last)));
+                const unsigned po = (unsigned)(2 * (p < PL ? GROUP * p + 8 * l : (REM ? o_last : off_last)));
                 typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
                 const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(sb + po);
                 pc[p].v = make_uint4(v.x, v.y, v.z, v.w);
@@ -360,7 +402,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 pc[p].w = __builtin_amdgcn_alignbit(raw[p].e, raw[p].v.w, sh);
             }
             compute(pc, it);
-            if (REM && l < REM_UNITS) keep[4 * it + g + 4][1 + l] = pc[NPC - 1];
+            if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = pc[NPC - 1];
         };
         // P, Q: pieces of the iteration at hand and of the next one, as read from the staged copy
         raw_piece P[NPC], Q[NPC];
@@ -388,7 +430,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     } else {
         auto run = [&](const uint4 (&d)[NBUF], int it) {
             compute(d, it);
-            if (REM && l < REM_UNITS) keep[4 * it + g + 4][1 + l] = d[NBUF - 1];
+            if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = d[NBUF - 1];
         };
         int it = it_begin;
         load(A, it);
@@ -412,16 +454,16 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- end of the run: slot i holds callback j0 - 4 + i ----
+    // ---- end of the run: slot i holds callback j0 - ROWS + i ----
     if (REM) {
-        // the callbacks' remainders, samples 128 PL .. L - 1, from the parked units
-        for (int sidx = lane + (it_begin < 0 ? 0 : 4); sidx < n_win + 4; sidx += 64) {
+        // the callbacks' remainders, samples GROUP PL .. L - 1, from the parked units
+        for (int sidx = lane + (it_begin < 0 ? 0 : ROWS); sidx < n_win + ROWS; sidx += 64) {
             bd_split_acc y;
             y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
             float ramax = 0.f;
-            bd_split_partial<NK, REM_UNITS>(keep[sidx] + 1, (int)L - 128 * PL, y, ramax);
-            bd_rot(y.a1, y.b1, 1 * 128 * PL);
-            bd_rot(y.a2, y.b2, 2 * 128 * PL);
+            bd_split_partial<NK, REM_UNITS>(keep[sidx] + 1, (int)L - GROUP * PL, y, ramax);
+            bd_rot(y.a1, y.b1, 1 * GROUP * PL);
+            bd_rot(y.a2, y.b2, 2 * GROUP * PL);
             bd_split_slot S = slots[sidx];
             S.re1 += y.a1; S.im1 += y.b1; S.re2 += y.a2; S.im2 += y.b2; S.dc += y.dc;
             S.amax = fmaxf(S.amax, ramax);
@@ -433,7 +475,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const uint64_t o0 = s * a.out_stride + (uint64_t)j0;
     __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, (unsigned)n_win);
     __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values ? a.values + o0 : nullptr, a.values ? (unsigned)n_win * 4u : 0u);
-    // lane i finishes callback j0 + i (slot i + 4)
+    // lane i finishes callback j0 + i (slot i + ROWS)
     for (int i = lane; i < n_win; i += 64) {
         const int64_t jj = j0 + i;
         const int q = (int)a.q, t = (int)a.tail_len;
@@ -441,13 +483,13 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         int xdc = 0;
         const int64_t jt = jj - q;                          // the callback whose tail opens the ring
         if (jt >= 0 && t > 0) {
-            const bd_split_slot T = slots[i + 4 - q];
+            const bd_split_slot T = slots[i + ROWS - q];
             // the piece that straddles the cut: its first m samples belong to the head
             const int m = c & 7;
             bd_split_acc hh;
             hh.a1 = hh.b1 = hh.a2 = hh.b2 = 0.f; hh.dc = 0;
             float unused = 0.f;
-            bd_split_partial<NK, 1>(keep[i + 4 - q], m, hh, unused);
+            bd_split_partial<NK, 1>(keep[i + ROWS - q], m, hh, unused);
             // anchored at the piece's first sample, c - m: move to the callback's first sample
             bd_rot(hh.a1, hh.b1, 1 * (c - m));
             bd_rot(hh.a2, hh.b2, 2 * (c - m));
@@ -460,7 +502,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         }
         for (int mm = 1; mm <= q; mm++) {
             if (jt + mm < 0) continue;                      // before the stream: zeros
-            const bd_split_slot S = slots[i + 4 - q + mm];
+            const bd_split_slot S = slots[i + ROWS - q + mm];
             float r1 = S.re1, i1 = S.im1, r2 = S.re2, i2 = S.im2;
             const int off = t + (mm - 1) * (int)L;
             bd_rot(r1, i1, 1 * off);
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         if (NK >= 1) best = fmaxf(best, sqrtf(xr1 * xr1 + xi1 * xi1));
         if (NK >= 2) best = fmaxf(best, sqrtf(xr2 * xr2 + xi2 * xi2));
         const float value = (a.divisor == 0.f) ? best : best / a.divisor;
-        const float wmax = fminf(slots[i + 4].amax, 32767.f);   // window_stats.rs:47
+        const float wmax = fminf(slots[i + ROWS].amax, 32767.f);   // window_stats.rs:47
         const bool flag = (wmax >= (float)a.min_amp) && (value > a.threshold);
         bd_store_stream_u8(rf, (unsigned)i, flag ? 1 : 0);
         bd_store_stream_f32(rv, (unsigned)i * 4u, value);       // a zero-sized descriptor drops the store
@@ -482,9 +524,9 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
 
 bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
 {
-    // bins 0 .. 2, no Nyquist packing; lengths that a row of 16 lanes x 24 .. 48 samples covers with most
-    // lanes busy and whose ring spans at most four callbacks (three whole ones and a tail)
-    if (callback_len <= 256 || callback_len >= 768) return false;
+    // bins 0 .. 2, no Nyquist packing; lengths that 16 lanes x 24 .. 48 samples (8 lanes x 24 .. 32 below 256)
+    // cover with most lanes busy and whose ring spans at most four (eight) callbacks
+    if (callback_len <= 128 || callback_len == 256 || callback_len >= 768) return false;
     return plan.last_bin <= 2 && !(plan.dc_packs_nyquist && plan.first_bin == 0);
 }
 
@@ -508,30 +550,53 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     a.head_len = callback_len - a.tail_len;
     a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
     a.divisor = plan.divisor; a.threshold = plan.threshold;
-    // 257 .. 341 samples: three whole callbacks in the ring; 342 .. 511: two; 512 .. 767: one.  The callback
-    // ends in group 2 (257 .. 383), 3 (385 .. 511), 4 (513 .. 639) or 5.  A remainder (samples past the last whole group)
-    // of at most BD_SPLIT_REM_MAX samples stays out of the main loop.
-    const int pstar = (int)(a.head_len / 128), pl = (int)(callback_len / 128);
-    const bool rem = (int)callback_len - 128 * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
+    // 385 .. 511 samples: two whole callbacks in the ring; 512 .. 767: one.  The callback ends in group 3
+    // (385 .. 511), 4 (513 .. 639) or 5.  A remainder (samples past the last whole group) of at most
+    // BD_SPLIT_REM_MAX samples stays out of the main loop.
+    // 129 .. 383 samples: eight lanes per callback (groups of 64 samples), two to seven whole callbacks in
+    // the ring; the last group is always a masked piece of the main loop.  (Sixteen lanes per callback were
+    // measured on 257 .. 383 as well: 4.0 .. 5.3 TB/s against 4.8 .. 5.8 with eight, which reduce over three
+    // lane steps instead of four and twice as many callbacks per iteration.)
+    const bool narrow = callback_len < 384;
+    const int group = narrow ? 64 : 128;
+    const int pstar = (int)(a.head_len / group), pl = (int)(callback_len / group);
+    const bool rem = !narrow && (int)callback_len - group * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
     const bool staged = callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE");
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-#define BD_SPLIT_GO(NK, PS, PLAST, RM) do { \
-        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM>), grid, dim3(64 * waves), 0, st, a); \
-        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM>), grid, dim3(64 * waves), 0, st, a); \
+#define BD_SPLIT_GO(NK, PS, PLAST, RM, LANES) do { \
+        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
+        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
         launched = true; } while (0)
 #define BD_SPLIT_PICK(NK) do { \
-        if (pl == 4 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 4, true); else BD_SPLIT_GO(NK, 0, 4, false); } \
-        else if (pl == 4 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 4, true); else BD_SPLIT_GO(NK, 1, 4, false); } \
-        else if (pl == 3 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 3, true); else BD_SPLIT_GO(NK, 1, 3, false); } \
-        else if (pl == 3 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 3, true); else BD_SPLIT_GO(NK, 2, 3, false); } \
-        else if (pl == 3 && pstar == 3) { BD_SPLIT_GO(NK, 3, 3, false); } \
-        else if (pl == 2 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 2, true); else BD_SPLIT_GO(NK, 0, 2, false); } \
-        else if (pl == 2 && pstar == 1) { BD_SPLIT_GO(NK, 1, 2, false); } \
-        else if (pl == 2 && pstar == 2) { BD_SPLIT_GO(NK, 2, 2, false); } \
-        else if (pl == 5 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 5, true); else BD_SPLIT_GO(NK, 2, 5, false); } \
-        else if (pl == 5 && pstar == 3) { BD_SPLIT_GO(NK, 3, 5, false); } } while (0)
+        if (narrow) { \
+            if (pl == 2 && pstar == 0) BD_SPLIT_GO(NK, 0, 2, false, 8); \
+            else if (pl == 2 && pstar == 1) BD_SPLIT_GO(NK, 1, 2, false, 8); \
+            else if (pl == 2 && pstar == 2) BD_SPLIT_GO(NK, 2, 2, false, 8); \
+            else if (pl == 3 && pstar == 0) BD_SPLIT_GO(NK, 0, 3, false, 8); \
+            else if (pl == 3 && pstar == 1) BD_SPLIT_GO(NK, 1, 3, false, 8); \
+            else if (pl == 3 && pstar == 2) BD_SPLIT_GO(NK, 2, 3, false, 8); \
+            else if (pl == 3 && pstar == 3) BD_SPLIT_GO(NK, 3, 3, false, 8); \
+            else if (pl == 4 && pstar == 0) BD_SPLIT_GO(NK, 0, 4, false, 8); \
+            else if (pl == 4 && pstar == 1) BD_SPLIT_GO(NK, 1, 4, false, 8); \
+            else if (pl == 4 && pstar == 2) BD_SPLIT_GO(NK, 2, 4, false, 8); \
+            else if (pl == 4 && pstar == 3) BD_SPLIT_GO(NK, 3, 4, false, 8); \
+            else if (pl == 4 && pstar == 4) BD_SPLIT_GO(NK, 4, 4, false, 8); \
+            else if (pl == 5 && pstar == 0) BD_SPLIT_GO(NK, 0, 5, false, 8); \
+            else if (pl == 5 && pstar == 1) BD_SPLIT_GO(NK, 1, 5, false, 8); \
+            else if (pl == 5 && pstar == 2) BD_SPLIT_GO(NK, 2, 5, false, 8); \
+            else if (pl == 5 && pstar == 3) BD_SPLIT_GO(NK, 3, 5, false, 8); \
+            else if (pl == 5 && pstar == 4) BD_SPLIT_GO(NK, 4, 5, false, 8); \
+            else if (pl == 5 && pstar == 5) BD_SPLIT_GO(NK, 5, 5, false, 8); \
+        } \
+        else if (pl == 4 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 4, true, 16); else BD_SPLIT_GO(NK, 0, 4, false, 16); } \
+        else if (pl == 4 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 4, true, 16); else BD_SPLIT_GO(NK, 1, 4, false, 16); } \
+        else if (pl == 3 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 3, true, 16); else BD_SPLIT_GO(NK, 1, 3, false, 16); } \
+        else if (pl == 3 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 3, true, 16); else BD_SPLIT_GO(NK, 2, 3, false, 16); } \
+        else if (pl == 3 && pstar == 3) { BD_SPLIT_GO(NK, 3, 3, false, 16); } \
+        else if (pl == 5 && pstar == 2) { if (rem) BD_SPLIT_GO(NK, 2, 5, true, 16); else BD_SPLIT_GO(NK, 2, 5, false, 16); } \
+        else if (pl == 5 && pstar == 3) { BD_SPLIT_GO(NK, 3, 5, false, 16); } } while (0)
     bool launched = false;
     if (plan.last_bin == 0) BD_SPLIT_PICK(0);
     else if (plan.last_bin == 1) BD_SPLIT_PICK(1);

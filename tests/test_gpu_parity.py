@@ -83,7 +83,7 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 100, 250, 255, 769, 790, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
+@pytest.mark.parametrize("L", [1, 7, 100, 125, 127, 769, 790, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
 def test_spectrum_window_callback_lengths(bd, oracle, L):
     """Callback lengths that are not multiples of 64 (or lie above 4096): the window kernel, with the
     callbacks whose ring starts before the stream on the generic kernel; streams of one callback, of a
@@ -102,7 +102,8 @@ def test_spectrum_window_callback_lengths(bd, oracle, L):
         _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
 
 
-@pytest.mark.parametrize("L", [257, 270, 280, 281, 300, 317, 319, 333, 341, 342, 350, 383, 385, 399,
+@pytest.mark.parametrize("L", [129, 130, 147, 150, 171, 191, 193, 200, 205, 221, 250, 255,
+                               257, 270, 280, 281, 300, 317, 319, 333, 341, 342, 350, 383, 385, 399,
                                400, 401, 450, 500, 511, 513, 517, 529, 532, 540, 552, 553, 600, 639,
                                641, 664, 665, 700, 720, 735, 767])
 def test_spectrum_split_kernel_callback_lengths(bd, oracle, L):
@@ -140,7 +141,7 @@ def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
     import torch
     rng = np.random.default_rng(1000 + seed)
     for _ in range(5):
-        L = int(rng.integers(257, 767))
+        L = int(rng.integers(129, 767))
         if L % 16 == 0 or L % 63 == 0:
             L += 1                      # lengths on a granule grid have kernels of their own
         streams = int(rng.integers(1, 7))
@@ -244,7 +245,7 @@ def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
 @pytest.mark.parametrize("sr", [8000, 16000, 22050, 48000, 96000, 192000])
 def test_spectrum_other_sampling_rates(bd, oracle, sr):
     x = _synth(bd, 2, 60000, first=5, sr=sr)
-    for L in (512, 1024, 600, 529, 300, 700, 270):      # the last five: every flavour of the split kernel above 32 kHz
+    for L in (512, 1024, 600, 529, 300, 700, 270, 200, 150):      # the last five: every flavour of the split kernel above 32 kHz
         _compare(bd, oracle, "Spectrum", sr, x, L)
 
 
