@@ -631,8 +631,12 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)
     // (more bins than three -- sampling rates below 32 kHz, down to 8 kHz -- as far as the granule
     // size allows; 512 and 1024 included then)
+    // (granules below 64 samples and of 63 samples only where the split kernel does not apply -- fewer than
+    // 129 samples, 768 and more, more than three bins: on 129 .. 767 it is faster than either: 144 4.1 against
+    // 3.2 TB/s, 240 5.2 / 3.2, 480 6.0 / 5.0, 441 5.1 / 5.0, 504 6.1 / 5.05, 756 6.2 / 5.05 at 16,384 streams)
+    const bool split_first = callback_len % 64 != 0 && bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT");
     const uint32_t gran = bd_spectrum_granule_size(callback_len);
-    if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) &&
+    if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) && !split_first &&
         !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
         // (granules of 63 samples for 63 q: 441, 882 below the window kernel's HBM-bound range)
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
@@ -659,7 +663,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         bd_set_last_kernel("bd_spectrum_generic_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_generic_kernel");
     };
-    // lengths around the reference's Linux callbacks (400 .. 640, off every grid): the split kernel, which
+    // 129 .. 767 samples off the 64-sample grid (the reference's Linux callbacks, 500 .. 540, among them): the split kernel, which
     // multiplies every sample by its twiddles once; the last callback of a stream goes to the generic kernel
     // (the split kernel's 16-byte loads may reach a few samples past a callback's end)
     if (window_path && bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT")) {

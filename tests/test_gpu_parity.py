@@ -102,7 +102,8 @@ def test_spectrum_window_callback_lengths(bd, oracle, L):
         _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
 
 
-@pytest.mark.parametrize("L", [129, 130, 147, 150, 171, 191, 193, 200, 205, 221, 250, 255,
+@pytest.mark.parametrize("L", [144, 160, 189, 240, 252, 288, 352, 441, 480, 504, 693, 756,
+                               129, 130, 147, 150, 171, 191, 193, 200, 205, 221, 250, 255,
                                257, 270, 280, 281, 300, 317, 319, 333, 341, 342, 350, 383, 385, 399,
                                400, 401, 450, 500, 511, 513, 517, 529, 532, 540, 552, 553, 600, 639,
                                641, 664, 665, 700, 720, 735, 767])
@@ -142,8 +143,8 @@ def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     for _ in range(5):
         L = int(rng.integers(129, 767))
-        if L % 16 == 0 or L % 63 == 0:
-            L += 1                      # lengths on a granule grid have kernels of their own
+        if L % 64 == 0:
+            L += 1                      # multiples of 64 have a kernel of their own
         streams = int(rng.integers(1, 7))
         n = int(rng.integers(2 * L, 200 * L))
         kw = {}
@@ -175,10 +176,12 @@ def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
 
 
 @pytest.mark.parametrize("L", [63, 126, 441, 504, 693, 819])
-def test_spectrum_granules_of_63_samples(bd, oracle, L):
+def test_spectrum_granules_of_63_samples(bd, oracle, monkeypatch, L):
     """Callback lengths 63 q up to 819 (441 = 10 ms at 44.1 kHz): granules of 63 samples; short streams,
-    partial steps, several runs, rows that are only 2-byte aligned, the unpinned choices."""
+    partial steps, several runs, rows that are only 2-byte aligned, the unpinned choices.  (With three
+    bins or fewer the split kernel takes 129 .. 767 samples by default: switched off here.)"""
     import torch
+    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")
     for n, streams in ((40000, 3), (4032 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4032 * 40 + 5, 1), (1024 + L, 2)):
         x = _synth(bd, streams, n, first=3)
         _compare(bd, oracle, "Spectrum", SR, x, L)
@@ -213,10 +216,12 @@ def test_spectrum_generic_kernel_alone(bd, oracle, monkeypatch, L):
 
 @pytest.mark.parametrize("L", [64, 128, 192, 256, 448, 960, 1536, 2048, 3008, 4096,
                                32, 96, 160, 480, 16, 48, 240])
-def test_spectrum_granule_callback_lengths(bd, oracle, L):
+def test_spectrum_granule_callback_lengths(bd, oracle, monkeypatch, L):
     """Multiples of 64 other than 512 / 1024, of 32 up to 512 and of 16 up to 256: the granule kernel
     (granules of 64, 32, 16 samples); short streams, partial steps,
-    a stream long enough to be split into runs, and the generic kernel on the same data."""
+    a stream long enough to be split into runs, and the generic kernel on the same data.  (With three
+    bins or fewer the split kernel takes 129 .. 767 samples off the 64-sample grid by default: switched off here.)"""
+    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")
     for n, streams in ((40000, 3), (4096 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4096 * 40 + 5, 1)):
         x = _synth(bd, streams, n, first=3)
         res, ref_v, _, _ = _compare(bd, oracle, "Spectrum", SR, x, L)
@@ -230,6 +235,7 @@ def test_spectrum_granule_callback_lengths(bd, oracle, L):
 
 def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
     import torch
+    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")     # 480 and 240 would take the split kernel
     x = torch.from_numpy(np.ascontiguousarray(np.pad(_synth(bd, 4, 4096 * 9 + 100, first=1), ((0, 0), (0, 28))))).cuda()
     n = 4096 * 9 + 100
     for L in (256, 2048, 704, 480, 240):
@@ -605,7 +611,8 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
     view[:, :n] = torch.from_numpy(x).cuda()
     assert view.data_ptr() % 4 == 2
     for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
-                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_g63_kernel"),
+                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_split_kernel"),
+                                 ("Spectrum", 819, "bd_spectrum_g63_kernel"),
                                  ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
         kind = bd.StrategyKind[kind_name]
         okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
