@@ -106,7 +106,7 @@ def test_spectrum_window_callback_lengths(bd, oracle, L):
                                129, 130, 147, 150, 171, 191, 193, 200, 205, 221, 250, 255,
                                257, 270, 280, 281, 300, 317, 319, 333, 341, 342, 350, 383, 385, 399,
                                400, 401, 450, 500, 511, 513, 517, 529, 532, 540, 552, 553, 600, 639,
-                               641, 664, 665, 700, 720, 735, 767])
+                               641, 664, 665, 700, 720, 735, 767, 576, 640, 704])
 def test_spectrum_split_kernel_callback_lengths(bd, oracle, L):
     """Callback lengths around what the reference's author sees on Linux ("mostly 500-540",
     spectrum.rs:40-42), on no grid: the split kernel (ring = tail of an earlier callback + whole
