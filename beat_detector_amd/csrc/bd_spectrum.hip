@@ -632,11 +632,14 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // (more bins than three -- sampling rates below 32 kHz, down to 8 kHz -- as far as the granule
     // size allows; 512 and 1024 included then)
     // (granules below 64 samples and of 63 samples only where the split kernel does not apply -- fewer than
-    // 129 samples, 768 and more, more than three bins: on 129 .. 767 it is faster than either: 144 4.1 against
+    // 129 samples, 768 and more, more than three bins: on 129 .. 767 it is faster than either: 144 3.8 against
     // 3.2 TB/s, 240 5.2 / 3.2, 480 6.0 / 5.0, 441 5.1 / 5.0, 504 6.1 / 5.05, 756 6.2 / 5.05 at 16,384 streams; of the multiples of 64 it takes 576, 640 and 704: 6.3 .. 6.6
-    // against 6.05 .. 6.15; 192 .. 448 are faster or as fast on granules of 64)
-    const bool split_first = (callback_len % 64 != 0 || callback_len > 512) && bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT");
+    // against 6.05 .. 6.15; 192 .. 448 are faster or as fast on granules of 64; below 129 samples it takes what is
+    // off the 32- and 63-sample grids: 100 3.65 TB/s (window kernel 1.0), 112 4.05 (granules of 16: 3.2), while 96
+    // stays on granules of 32 at 4.6)
     const uint32_t gran = bd_spectrum_granule_size(callback_len);
+    const bool split_first = (callback_len % 64 != 0 || callback_len > 512) && !(callback_len < 129 && gran >= 32) &&
+                             bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT");
     if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) && !split_first &&
         !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
         // (granules of 63 samples for 63 q: 441, 882 below the window kernel's HBM-bound range)

@@ -1,4 +1,4 @@
-// Spectrum strategy, batched, for callback lengths of 129 .. 767 samples that sit on no
+// Spectrum strategy, batched, for callback lengths of 65 .. 767 samples that sit on no
 // grid (the reference's author reports "mostly 500-540" samples per callback on Linux,
 // src/strategies/spectrum.rs:40-42; 1024 elsewhere).
 //
@@ -145,19 +145,25 @@ template <> struct bd_split_tw<8> {
     static __device__ __forceinline__ constexpr float C(int k, int i) { return BD_SP8_C[k][i]; }
     static __device__ __forceinline__ constexpr float S(int k, int i) { return BD_SP8_S[k][i]; }
 };
+template <> struct bd_split_tw<4> {
+    static __device__ __forceinline__ constexpr float C(int k, int i) { return BD_SP4_C[k][i]; }
+    static __device__ __forceinline__ constexpr float S(int k, int i) { return BD_SP4_S[k][i]; }
+};
 
-// Sum / maximum over the LPC lanes of a callback, valid in all of them.  Groups of 8 lanes: partners
-// l ^ 1, l ^ 2, then the mirror inside the half-row (the other quad's sum).
+// Sum / maximum over the LPC lanes of a callback, valid in all of them.  Groups of 4 lanes: partners
+// l ^ 1, l ^ 2; of 8 lanes: then the mirror inside the half-row (the other quad's sum).
 template <int LPC> __device__ __forceinline__ float bd_group_sum(float v)
 {
     if constexpr (LPC == 16) return bd_row_sum(v);
-    v += bd_dpp_f<0xB1>(v); v += bd_dpp_f<0x4E>(v); v += bd_dpp_f<0x141>(v);
+    v += bd_dpp_f<0xB1>(v); v += bd_dpp_f<0x4E>(v);
+    if constexpr (LPC == 8) v += bd_dpp_f<0x141>(v);
     return v;
 }
 template <int LPC> __device__ __forceinline__ int bd_group_sum(int v)
 {
     if constexpr (LPC == 16) return bd_row_sum(v);
-    v += bd_dpp_i<0xB1>(v); v += bd_dpp_i<0x4E>(v); v += bd_dpp_i<0x141>(v);
+    v += bd_dpp_i<0xB1>(v); v += bd_dpp_i<0x4E>(v);
+    if constexpr (LPC == 8) v += bd_dpp_i<0x141>(v);
     return v;
 }
 template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
@@ -165,7 +171,8 @@ template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
     if constexpr (LPC == 16) {
         return bd_row_max(v);
     } else {
-        v = fmaxf(v, bd_dpp_f<0xB1>(v)); v = fmaxf(v, bd_dpp_f<0x4E>(v)); v = fmaxf(v, bd_dpp_f<0x141>(v));
+        v = fmaxf(v, bd_dpp_f<0xB1>(v)); v = fmaxf(v, bd_dpp_f<0x4E>(v));
+        if constexpr (LPC == 8) v = fmaxf(v, bd_dpp_f<0x141>(v));
         return v;
     }
 }
@@ -185,7 +192,8 @@ template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
 // one more dword, and a funnel shift by 16 bits in the rows that start on an odd sample.
 // LPC: lanes per callback.  16 (groups of 128 samples, four callbacks per iteration) for callbacks of 385
 // samples and more; 8 (groups of 64 samples, eight callbacks per iteration) for 129 .. 383 samples, whose
-// ring spans up to seven whole callbacks.
+// ring spans up to seven whole callbacks; 4 (groups of 32 samples, sixteen callbacks per iteration) for
+// 65 .. 127 samples: up to fifteen whole callbacks.
 template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16>
 __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_split_kernel(bd_split_args a)
 {
@@ -526,7 +534,7 @@ bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
 {
     // bins 0 .. 2, no Nyquist packing; lengths that 16 lanes x 24 .. 48 samples (8 lanes x 24 .. 32 below 256)
     // cover with most lanes busy and whose ring spans at most four (eight) callbacks
-    if (callback_len <= 128 || callback_len == 256 || callback_len >= 768) return false;
+    if (callback_len <= 64 || callback_len == 128 || callback_len == 256 || callback_len >= 768) return false;
     return plan.last_bin <= 2 && !(plan.dc_packs_nyquist && plan.first_bin == 0);
 }
 
@@ -553,15 +561,18 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     // 385 .. 511 samples: two whole callbacks in the ring; 512 .. 767: one.  The callback ends in group 3
     // (385 .. 511), 4 (513 .. 639) or 5.  A remainder (samples past the last whole group) of at most
     // BD_SPLIT_REM_MAX samples stays out of the main loop.
+    // 65 .. 127 samples: four lanes per callback (groups of 32 samples), eight to fifteen whole callbacks.
     // 129 .. 383 samples: eight lanes per callback (groups of 64 samples), two to seven whole callbacks in
     // the ring; the last group is always a masked piece of the main loop.  (Sixteen lanes per callback were
     // measured on 257 .. 383 as well: 4.0 .. 5.3 TB/s against 4.8 .. 5.8 with eight, which reduce over three
     // lane steps instead of four and twice as many callbacks per iteration.)
-    const bool narrow = callback_len < 384;
-    const int group = narrow ? 64 : 128;
+    const bool narrow = callback_len < 384, narrow4 = callback_len < 128;
+    const int group = narrow4 ? 32 : (narrow ? 64 : 128);
     const int pstar = (int)(a.head_len / group), pl = (int)(callback_len / group);
     const bool rem = !narrow && (int)callback_len - group * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
-    const bool staged = callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE");
+    // the narrow variants always stage (a row of 4 or 8 lanes loads only 64 or 128 contiguous bytes per
+    // instruction: 100 samples 3.0 -> 3.5 TB/s, 300 4.6 -> 5.2 with the staged copy's whole-line loads)
+    const bool staged = narrow || (callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE"));
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
@@ -569,26 +580,38 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
         if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
         else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
         launched = true; } while (0)
+#define BD_SPLIT_GO_ST(NK, PS, PLAST, LANES) do { \
+        hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, false, LANES>), grid, dim3(64 * waves), 0, st, a); \
+        launched = true; } while (0)
 #define BD_SPLIT_PICK(NK) do { \
-        if (narrow) { \
-            if (pl == 2 && pstar == 0) BD_SPLIT_GO(NK, 0, 2, false, 8); \
-            else if (pl == 2 && pstar == 1) BD_SPLIT_GO(NK, 1, 2, false, 8); \
-            else if (pl == 2 && pstar == 2) BD_SPLIT_GO(NK, 2, 2, false, 8); \
-            else if (pl == 3 && pstar == 0) BD_SPLIT_GO(NK, 0, 3, false, 8); \
-            else if (pl == 3 && pstar == 1) BD_SPLIT_GO(NK, 1, 3, false, 8); \
-            else if (pl == 3 && pstar == 2) BD_SPLIT_GO(NK, 2, 3, false, 8); \
-            else if (pl == 3 && pstar == 3) BD_SPLIT_GO(NK, 3, 3, false, 8); \
-            else if (pl == 4 && pstar == 0) BD_SPLIT_GO(NK, 0, 4, false, 8); \
-            else if (pl == 4 && pstar == 1) BD_SPLIT_GO(NK, 1, 4, false, 8); \
-            else if (pl == 4 && pstar == 2) BD_SPLIT_GO(NK, 2, 4, false, 8); \
-            else if (pl == 4 && pstar == 3) BD_SPLIT_GO(NK, 3, 4, false, 8); \
-            else if (pl == 4 && pstar == 4) BD_SPLIT_GO(NK, 4, 4, false, 8); \
-            else if (pl == 5 && pstar == 0) BD_SPLIT_GO(NK, 0, 5, false, 8); \
-            else if (pl == 5 && pstar == 1) BD_SPLIT_GO(NK, 1, 5, false, 8); \
-            else if (pl == 5 && pstar == 2) BD_SPLIT_GO(NK, 2, 5, false, 8); \
-            else if (pl == 5 && pstar == 3) BD_SPLIT_GO(NK, 3, 5, false, 8); \
-            else if (pl == 5 && pstar == 4) BD_SPLIT_GO(NK, 4, 5, false, 8); \
-            else if (pl == 5 && pstar == 5) BD_SPLIT_GO(NK, 5, 5, false, 8); \
+        if (narrow4) { \
+            if (pl == 2 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 2, 4); \
+            else if (pl == 2 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 2, 4); \
+            else if (pl == 2 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 2, 4); \
+            else if (pl == 3 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 3, 4); \
+            else if (pl == 3 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 3, 4); \
+            else if (pl == 3 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 3, 4); \
+            else if (pl == 3 && pstar == 3) BD_SPLIT_GO_ST(NK, 3, 3, 4); \
+        } \
+        else if (narrow) { \
+            if (pl == 2 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 2, 8); \
+            else if (pl == 2 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 2, 8); \
+            else if (pl == 2 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 2, 8); \
+            else if (pl == 3 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 3, 8); \
+            else if (pl == 3 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 3, 8); \
+            else if (pl == 3 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 3, 8); \
+            else if (pl == 3 && pstar == 3) BD_SPLIT_GO_ST(NK, 3, 3, 8); \
+            else if (pl == 4 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 4, 8); \
+            else if (pl == 4 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 4, 8); \
+            else if (pl == 4 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 4, 8); \
+            else if (pl == 4 && pstar == 3) BD_SPLIT_GO_ST(NK, 3, 4, 8); \
+            else if (pl == 4 && pstar == 4) BD_SPLIT_GO_ST(NK, 4, 4, 8); \
+            else if (pl == 5 && pstar == 0) BD_SPLIT_GO_ST(NK, 0, 5, 8); \
+            else if (pl == 5 && pstar == 1) BD_SPLIT_GO_ST(NK, 1, 5, 8); \
+            else if (pl == 5 && pstar == 2) BD_SPLIT_GO_ST(NK, 2, 5, 8); \
+            else if (pl == 5 && pstar == 3) BD_SPLIT_GO_ST(NK, 3, 5, 8); \
+            else if (pl == 5 && pstar == 4) BD_SPLIT_GO_ST(NK, 4, 5, 8); \
+            else if (pl == 5 && pstar == 5) BD_SPLIT_GO_ST(NK, 5, 5, 8); \
         } \
         else if (pl == 4 && pstar == 0) { if (rem) BD_SPLIT_GO(NK, 0, 4, true, 16); else BD_SPLIT_GO(NK, 0, 4, false, 16); } \
         else if (pl == 4 && pstar == 1) { if (rem) BD_SPLIT_GO(NK, 1, 4, true, 16); else BD_SPLIT_GO(NK, 1, 4, false, 16); } \
@@ -602,6 +625,7 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     else if (plan.last_bin == 1) BD_SPLIT_PICK(1);
     else BD_SPLIT_PICK(2);
 #undef BD_SPLIT_PICK
+#undef BD_SPLIT_GO_ST
 #undef BD_SPLIT_GO
     if (!launched) { bd_set_error("callback length %u outside the split kernel's range", callback_len); return BD_ERR_UNSUPPORTED; }
     bd_set_last_kernel("bd_spectrum_split_kernel");
