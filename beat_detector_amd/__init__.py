@@ -40,6 +40,7 @@ from .api import (  # noqa: F401
     stereo_to_mono,
     synth_fill,
     synth_fill_host,
+    tuning,
     u16_data_to_i16,
 )
 from .onset import OnsetResult, onset_batch, onset_frames, onset_pick, onset_stft  # noqa: F401,E402

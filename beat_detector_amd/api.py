@@ -6,6 +6,7 @@ handed to the library) and the current HIP stream.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import enum
 import os
@@ -191,9 +192,11 @@ def lib() -> C.CDLL:
         "bd_synth_fill": (i32, [vp, u64, u64, u64, u64, u64, u32, vp]),
         "bd_synth_fill_host": (i32, [vp, u64, u64, u64, u64, u64, u32]),
         "bd_last_kernel_name": (C.c_char_p, []),
+        "bd_tuning_reload": (None, []),
         "bd_live_create": (i32, [i32, u32, pp, u32, u32, u32, i32, C.POINTER(vp)]),
         "bd_live_set_on_beat": (i32, [vp, LIVE_ON_BEAT_FN, vp]),
         "bd_live_submit": (i32, [vp, vp, u32, i32, C.POINTER(u64)]),
+        "bd_live_submit_ragged": (i32, [vp, vp, vp, u32, i32, C.POINTER(u64)]),
         "bd_live_poll": (i32, [vp, u64, i32, vp, vp, vp]),
         "bd_live_destroy": (None, [vp]),
         "bd_start_listening": (i32, [ON_BEAT_FN, vp, C.POINTER(InputSource), i32, C.POINTER(C.c_int), C.POINTER(vp)]),
@@ -231,7 +234,7 @@ EXPORTED_SYMBOLS = (
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_noalloc bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
     "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
-    "bd_synth_fill_host bd_last_kernel_name bd_live_create bd_live_set_on_beat bd_live_submit bd_live_poll "
+    "bd_synth_fill_host bd_last_kernel_name bd_tuning_reload bd_live_create bd_live_set_on_beat bd_live_submit bd_live_submit_ragged bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
     "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope bd_probe_read bd_probe_read_ex "
     "bd_chunk_source_synth bd_chunked_create bd_chunked_device_bytes bd_chunked_analyze bd_chunked_onset bd_chunked_last_timing bd_chunked_destroy"
@@ -260,6 +263,32 @@ def device_name(device: int):
 
 def last_kernel_name() -> str:
     return lib().bd_last_kernel_name().decode()
+
+
+@contextlib.contextmanager
+def tuning(**switches):
+    """Sets the library's experiment switches (environment variables BD_*, named here in lower case
+    without the prefix: tuning(spec_no_split=1)) for the calls inside the block.  The library reads
+    its environment once; this publishes the changed environment with bd_tuning_reload and restores
+    the previous one afterwards.  A value of None removes the variable.  Tests and experiment drivers only."""
+    saved = {}
+    for k, v in switches.items():
+        name = "BD_" + k.upper()
+        saved[name] = os.environ.get(name)
+        if v is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(v)
+    lib().bd_tuning_reload()
+    try:
+        yield
+    finally:
+        for name, v in saved.items():
+            if v is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = v
+        lib().bd_tuning_reload()
 
 
 # --------------------------------------------------------------------------
@@ -649,6 +678,18 @@ class Live:
             raise BeatDetectorError(BD_ERR_INVALID_ARG, "samples must be [n_streams, n]")
         tick = C.c_uint64(0)
         _check(lib().bd_live_submit(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], fmt, C.byref(tick)))
+        return tick.value
+
+    def submit_ragged(self, samples, lengths, fmt: int = FMT_I16) -> int:
+        """One tick with a callback length per stream (bd_live_submit_ragged): `samples` is
+        [n_streams, row_pitch], stream m's callback the first lengths[m] samples of row m; 0 skips the stream."""
+        a = np.ascontiguousarray(samples, dtype=_FMT_DTYPE[fmt])
+        n = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if a.ndim != 2 or a.shape[0] != self.n_streams or n.shape != (self.n_streams,):
+            raise BeatDetectorError(BD_ERR_INVALID_ARG, "samples must be [n_streams, row_pitch], lengths [n_streams]")
+        tick = C.c_uint64(0)
+        _check(lib().bd_live_submit_ragged(self._h, a.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p),
+                                           a.shape[1], fmt, C.byref(tick)))
         return tick.value
 
     def poll(self, tick: int, wait: bool = True):

@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -73,6 +75,52 @@ extern "C" int bd_device_name(int device, char *name, size_t capacity, uint64_t 
     snprintf(name, capacity, "%s (%s)", prop.name, prop.gcnArchName);
     if (total_memory_bytes) *total_memory_bytes = (uint64_t)prop.totalGlobalMem;
     return BD_OK;
+}
+
+// ---- experiment switches -----------------------------------------------------------
+// One immutable snapshot of the BD_* environment variables; launch paths only dereference a pointer.
+// bd_tuning_reload() publishes a new snapshot (the old ones stay allocated: launches running on
+// other threads may still read them; a reload happens a handful of times in a test process).
+static std::atomic<const bd_tuning *> bd_tuning_now{nullptr};
+static std::mutex bd_tuning_mutex;
+
+static const bd_tuning *bd_tuning_read()
+{
+    auto num = [](const char *name) -> long long { const char *v = getenv(name); return v ? atoll(v) : 0; };
+    auto set = [](const char *name) -> int { return getenv(name) != nullptr; };
+    bd_tuning *t = new bd_tuning();
+    t->spec_force_granule = set("BD_SPEC_FORCE_GRANULE");
+    t->spec_run = (int)num("BD_SPEC_RUN");
+    const long long pad = num("BD_SPEC_LDS_PAD");
+    t->spec_lds_pad = pad < 0 ? 0u : (pad > 150000 ? 150000u : (unsigned)pad);
+    t->spec_no_split = set("BD_SPEC_NO_SPLIT");
+    t->spec_no_granule = set("BD_SPEC_NO_GRANULE");
+    t->spec_no_small_granule = set("BD_SPEC_NO_SMALL_GRANULE");
+    t->spec_store = (int)num("BD_SPEC_STORE");
+    t->split_no_rem = set("BD_SPLIT_NO_REM");
+    t->split_no_stage = set("BD_SPLIT_NO_STAGE");
+    t->lpf_variant = (int)num("BD_LPF_VARIANT");
+    const long long thr = num("BD_HOST_THREADS");
+    t->host_threads = thr > 0 ? (unsigned)thr : 0u;
+    const long long chunk = num("BD_HOST_CHUNK_BYTES");
+    t->host_chunk_bytes = chunk > 0 ? (uint64_t)chunk : 0ull;
+    return t;
+}
+
+const bd_tuning &bd_tuning_get()
+{
+    const bd_tuning *t = bd_tuning_now.load(std::memory_order_acquire);
+    if (t) return *t;
+    std::lock_guard<std::mutex> lock(bd_tuning_mutex);
+    t = bd_tuning_now.load(std::memory_order_acquire);
+    if (!t) { t = bd_tuning_read(); bd_tuning_now.store(t, std::memory_order_release); }
+    return *t;
+}
+
+extern "C" void bd_tuning_reload(void)
+{
+    std::lock_guard<std::mutex> lock(bd_tuning_mutex);
+    bd_tuning_now.store(bd_tuning_read(), std::memory_order_release);
 }
 
 // ---- parameters and plan ----------------------------------------------------------
@@ -353,8 +401,8 @@ static thread_local unsigned bd_host_pack_share = 1;
 static void bd_host_pack(int16_t *dst, uint64_t d_stride, const int16_t *src, uint64_t stride, uint64_t n_samples,
                          uint64_t rows)
 {
-    const char *env = getenv("BD_HOST_THREADS"); // tuning knob
-    unsigned want = env && atoi(env) > 0 ? (unsigned)atoi(env) : BD_HOST_PACK_THREADS;
+    const unsigned knob = bd_tuning_get().host_threads;
+    unsigned want = knob ? knob : BD_HOST_PACK_THREADS;
     want = want / bd_host_pack_share ? want / bd_host_pack_share : 1;
     const unsigned n_thr = rows >= 4 * want ? want : 1;
     auto work = [=](unsigned t) {
@@ -382,8 +430,8 @@ static int bd_host_run(bd_host_job &j, int kind, uint32_t sampling_rate, const b
     // boundary: the fast kernels apply and every load / store covers whole lines
     const uint64_t d_stride = (n_samples + 63) & ~63ull;
     const uint64_t o_stride = (n_cb + 127) & ~127ull;
-    const char *chunk_env = getenv("BD_HOST_CHUNK_BYTES"); // tests use small chunks to exercise the pipeline
-    const uint64_t chunk_bytes = chunk_env && atoll(chunk_env) > 0 ? (uint64_t)atoll(chunk_env) : BD_HOST_CHUNK_BYTES;
+    const uint64_t chunk_knob = bd_tuning_get().host_chunk_bytes; // tests use small chunks to exercise the pipeline
+    const uint64_t chunk_bytes = chunk_knob ? chunk_knob : BD_HOST_CHUNK_BYTES;
     uint64_t chunk = chunk_bytes / (d_stride * sizeof(int16_t));
     if (chunk < 1) chunk = 1;
     if (chunk > n_streams) chunk = n_streams;

@@ -37,6 +37,25 @@ void bd_set_error(const char *fmt, ...);
 void bd_set_last_kernel(const char *name);
 int  bd_check_hip(hipError_t e, const char *what);
 
+// Experiment switches.  They are read from the environment once, when the library first needs
+// them, never on a launch path; bd_tuning_reload() (tests and experiment drivers) reads them again.
+// Defaults (every variable unset) are the measured best and are what a program gets.
+struct bd_tuning {
+    int      spec_force_granule;     // BD_SPEC_FORCE_GRANULE: 512 / 1024 through the granule kernel
+    int      spec_run;               // BD_SPEC_RUN: half-blocks per task of the half-block kernel (0 = automatic)
+    unsigned spec_lds_pad;           // BD_SPEC_LDS_PAD: unused dynamic LDS, caps the half-block kernel's residency
+    int      spec_no_split;          // BD_SPEC_NO_SPLIT: no split kernel
+    int      spec_no_granule;        // BD_SPEC_NO_GRANULE: generic kernel for everything off the half-block path
+    int      spec_no_small_granule;  // BD_SPEC_NO_SMALL_GRANULE: no granules below 64 samples
+    int      spec_store;             // BD_SPEC_STORE: result-store variant of the half-block kernel (0 = default)
+    int      split_no_rem;           // BD_SPLIT_NO_REM: remainder as a masked piece of the main loop
+    int      split_no_stage;         // BD_SPLIT_NO_STAGE: no LDS staging for lengths that are not multiples of 4
+    int      lpf_variant;            // BD_LPF_VARIANT: chunk size / wavefronts per workgroup
+    unsigned host_threads;           // BD_HOST_THREADS: packing threads of bd_analyze_batch_host (0 = default)
+    uint64_t host_chunk_bytes;       // BD_HOST_CHUNK_BYTES: staging chunk of bd_analyze_batch_host (0 = default)
+};
+const bd_tuning &bd_tuning_get();
+
 #define BD_HIP(call) do { int _s = bd_check_hip((call), #call); if (_s != BD_OK) return _s; } while (0)
 
 // stage launchers (device pointers, enqueue only)

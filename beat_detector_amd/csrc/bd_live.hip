@@ -40,9 +40,13 @@ struct bd_live_result {
 // What changes from tick to tick, in pinned host memory that the kernels read through its
 // device address: a captured graph never has to be rebuilt or updated for a new callback length.
 struct bd_live_ctl {
-    uint32_t n;             // samples per stream in this tick
+    uint32_t n;             // samples per stream in this tick (equal callbacks)
+    uint32_t ragged;        // 1: stream m brings len[m] samples, rows are `pitch` samples apart
+    uint32_t pitch;
     uint32_t reserved;
+    uint32_t len[1];        // [n_streams] (the block is allocated with room for them)
 };
+static size_t bd_live_ctl_bytes(size_t n_streams) { return sizeof(bd_live_ctl) + (n_streams ? n_streams - 1 : 0) * sizeof(uint32_t); }
 
 struct bd_live_args {
     const int16_t  *in;     // [M][in_stride]
@@ -104,8 +108,20 @@ __global__ __launch_bounds__(256) void bd_live_tick_kernel(bd_live_args a)
     __shared__ uint32_t sh_allowed;
     const int16_t *stage = reinterpret_cast<const int16_t *>(stage_u4);
     const uint32_t m = blockIdx.x, tid = threadIdx.x;
-    const uint32_t n = a.ctl ? a.ctl->n : a.n;
-    const uint64_t in_stride = a.ctl ? (uint64_t)n : a.in_stride;
+    // every stream is its own device in the reference and its closure gets its own data.len()
+    // (src/record.rs:93-95, :107-109, :121-123): a tick may bring a different length per stream
+    const bool ragged = a.ctl && a.ctl->ragged;
+    const uint32_t n = a.ctl ? (ragged ? a.ctl->len[m] : a.ctl->n) : a.n;
+    const uint64_t in_stride = a.ctl ? (uint64_t)(ragged ? a.ctl->pitch : n) : a.in_stride;
+    if (n == 0) {
+        // the stream's device delivered nothing in this tick: no is_beat call, nothing advances
+        if (tid == 0) {
+            bd_live_result r;
+            r.beat = 0u; r.relative_ms = 0u; r.value = 0.f; r.candidate = 0u;
+            a.result[m] = r;
+        }
+        return;
+    }
     const int16_t *in = a.in + (uint64_t)m * in_stride;
     int16_t *ring = a.ring + (uint64_t)m * BD_RING_LEN;
     bd_live_state st = a.state[m];
@@ -368,7 +384,8 @@ extern "C" int bd_detector_last(const bd_detector *d, float *value, int *candida
 // the tick's own length comes from the control block.
 __global__ void bd_live_convert_kernel(const void *in, int16_t *out, const bd_live_ctl *ctl, uint32_t n_streams, int format)
 {
-    const uint64_t n = (uint64_t)n_streams * ctl->n;
+    // rows of a ragged tick are converted whole (what lies past a stream's own samples is not looked at)
+    const uint64_t n = (uint64_t)n_streams * (ctl->ragged ? ctl->pitch : ctl->n);
     const uint64_t i = bd_block_index() * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (format == BD_FMT_U16) {
@@ -527,11 +544,11 @@ static int bd_live_init(bd_live *L)
     L->slots.resize(L->depth);
     for (auto &s : L->slots) {
         BD_HIP(hipHostMalloc(&s.h_in, M * cap * 4, hipHostMallocDefault));
-        BD_HIP(hipHostMalloc((void **)&s.h_ctl, sizeof(bd_live_ctl), hipHostMallocDefault));
+        BD_HIP(hipHostMalloc((void **)&s.h_ctl, bd_live_ctl_bytes(M), hipHostMallocDefault));
         BD_HIP(hipMalloc((void **)&s.d_i16, M * cap * sizeof(int16_t)));
         BD_HIP(hipHostMalloc((void **)&s.h_res, M * sizeof(bd_live_result), hipHostMallocDefault));
         BD_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        s.h_ctl->n = 0; s.h_ctl->reserved = 0;
+        memset(s.h_ctl, 0, bd_live_ctl_bytes(M));
     }
     BD_HIP(hipStreamSynchronize(L->stream));
     // every graph a tick can need exists before the first tick
@@ -587,12 +604,11 @@ extern "C" int bd_live_set_on_beat(bd_live *L, bd_live_on_beat_fn cb, void *user
     return BD_OK;
 }
 
-extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int format, uint64_t *tick_id)
+// One tick: equal callbacks (lengths == NULL, `n` samples per stream, rows n apart) or one length per
+// stream (rows `n` = pitch samples apart).
+static int bd_live_submit_impl(bd_live *L, const void *samples, uint32_t n, const uint32_t *lengths, int format,
+                               uint64_t *tick_id)
 {
-    if (!L || !samples) { bd_set_error("bd_live_submit: null argument"); return BD_ERR_INVALID_ARG; }
-    if (n == 0) { bd_set_error("empty window (the reference panics at window_stats.rs:51)"); return BD_ERR_EMPTY_WINDOW; }
-    if (n > L->max_len) { bd_set_error("callback of %u samples exceeds max_callback_len %u", n, L->max_len); return BD_ERR_INVALID_ARG; }
-    if (format != BD_FMT_I16 && format != BD_FMT_U16 && format != BD_FMT_F32) { bd_set_error("unknown sample format %d", format); return BD_ERR_INVALID_ARG; }
     uint64_t tick;
     bd_live_slot *s;
     {
@@ -612,7 +628,12 @@ extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int f
     if (prev != L->device) BD_HIP(hipSetDevice(L->device));
     const size_t elem = format == BD_FMT_F32 ? 4 : 2;
     memcpy(s->h_in, samples, (size_t)L->n_streams * n * elem);
-    s->h_ctl->n = n;
+    if (lengths) {
+        s->h_ctl->n = 0; s->h_ctl->ragged = 1; s->h_ctl->pitch = n;
+        memcpy(s->h_ctl->len, lengths, (size_t)L->n_streams * sizeof(uint32_t));
+    } else {
+        s->h_ctl->n = n; s->h_ctl->ragged = 0; s->h_ctl->pitch = n;
+    }
     int st = bd_check_hip(hipGraphLaunch(s->graph[format], L->stream), "launch live tick graph");
     if (st == BD_OK) st = bd_check_hip(hipEventRecord(s->done, L->stream), "record tick event");
     if (prev != L->device) (void)hipSetDevice(prev);
@@ -625,6 +646,30 @@ extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int f
     L->cv.notify_all();
     if (tick_id) *tick_id = tick;
     return BD_OK;
+}
+
+extern "C" int bd_live_submit(bd_live *L, const void *samples, uint32_t n, int format, uint64_t *tick_id)
+{
+    if (!L || !samples) { bd_set_error("bd_live_submit: null argument"); return BD_ERR_INVALID_ARG; }
+    if (n == 0) { bd_set_error("empty window (the reference panics at window_stats.rs:51)"); return BD_ERR_EMPTY_WINDOW; }
+    if (n > L->max_len) { bd_set_error("callback of %u samples exceeds max_callback_len %u", n, L->max_len); return BD_ERR_INVALID_ARG; }
+    if (format != BD_FMT_I16 && format != BD_FMT_U16 && format != BD_FMT_F32) { bd_set_error("unknown sample format %d", format); return BD_ERR_INVALID_ARG; }
+    return bd_live_submit_impl(L, samples, n, nullptr, format, tick_id);
+}
+
+extern "C" int bd_live_submit_ragged(bd_live *L, const void *samples, const uint32_t *n_per_stream, uint32_t row_pitch,
+                                     int format, uint64_t *tick_id)
+{
+    if (!L || !samples || !n_per_stream) { bd_set_error("bd_live_submit_ragged: null argument"); return BD_ERR_INVALID_ARG; }
+    if (row_pitch == 0) { bd_set_error("bd_live_submit_ragged: row_pitch must be positive"); return BD_ERR_INVALID_ARG; }
+    if (row_pitch > L->max_len) { bd_set_error("row pitch of %u samples exceeds max_callback_len %u", row_pitch, L->max_len); return BD_ERR_INVALID_ARG; }
+    if (format != BD_FMT_I16 && format != BD_FMT_U16 && format != BD_FMT_F32) { bd_set_error("unknown sample format %d", format); return BD_ERR_INVALID_ARG; }
+    for (uint32_t m = 0; m < L->n_streams; m++)
+        if (n_per_stream[m] > row_pitch) {
+            bd_set_error("stream %u: callback of %u samples exceeds the row pitch %u", m, n_per_stream[m], row_pitch);
+            return BD_ERR_INVALID_ARG;
+        }
+    return bd_live_submit_impl(L, samples, row_pitch, n_per_stream, format, tick_id);
 }
 
 extern "C" int bd_live_poll(bd_live *L, uint64_t tick_id, int wait, uint8_t *beats, uint32_t *relative_ms,

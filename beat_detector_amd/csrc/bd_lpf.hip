@@ -260,8 +260,7 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
                          (callback_len % 64 == 0 || callback_len < 256);
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
-    const char *variant_str = getenv("BD_LPF_VARIANT");
-    const int variant_env = variant_str ? atoi(variant_str) : 0;
+    const int variant_env = bd_tuning_get().lpf_variant;
     const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
     const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
     const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;

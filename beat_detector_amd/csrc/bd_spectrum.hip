@@ -31,8 +31,6 @@
 //   One wavefront per callback, twiddles from a 1024-entry table.
 #include "bd_internal.h"
 
-#include <stdio.h>
-#include <stdlib.h>
 #include "bd_twiddles.inc"
 #include "bd_granule_tw.inc"
 
@@ -53,6 +51,7 @@ struct bd_spec_args {
     uint32_t       include_dc;
     float          divisor;
     float          threshold;
+    uint32_t       store_mode;      // result-store variant; only builds with BD_STORE_EXPERIMENT look at it
 };
 
 static __device__ const float bd_cos1024[1024] = {
@@ -70,20 +69,33 @@ __device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int
     for (int c = 0; c < 4; c++) d[c] = bd_load_stream16(p + 16 * c);
 }
 
+#ifndef BD_SPEC_MAX_RUN
 #define BD_SPEC_MAX_RUN 128 // half-blocks per task, upper bound (LDS slots of a run)
+#endif
 
-// Sums of one half-block, parked in LDS until the end of the run.
-struct __attribute__((aligned(16))) bd_spec_slot {
-    float re1, im1, re2, im2;
-    int   dc, ny;
-    float amax, pad;
+// Sums of one half-block, parked in LDS until the end of the run: two planes of 16-byte entries.
+// At the end of the run lane i reads the entries of callback i with 16-byte LDS reads; entries 16 bytes
+// apart put the 16 lanes that such a read serves together on 64 different banks (one 32-byte record
+// per half-block put two of them on every bank).  Half-block h of the run sits at entry
+// bd_spec_entry(h): as it comes for 512-sample callbacks (lane i reads h = i, i + 1), even and odd
+// half-blocks in two halves of the plane for 1024-sample callbacks (lane i reads h = 2 i, 2 i + 1).
+struct __attribute__((aligned(16))) bd_spec_sums { float re1, im1, re2, im2; };
+struct __attribute__((aligned(16))) bd_spec_misc { int dc, ny; float amax, pad; };
+#define BD_SPEC_SLOTS (BD_SPEC_MAX_RUN + 4)
+struct bd_spec_slots {
+    bd_spec_sums sums[BD_SPEC_SLOTS];
+    bd_spec_misc misc[BD_SPEC_SLOTS];
 };
+template <int MODE> __device__ __forceinline__ int bd_spec_entry(int h)
+{
+    return MODE == 0 ? h : ((h & 1) * (BD_SPEC_SLOTS / 2) + (h >> 1));
+}
 
 // One iteration: four half-blocks (one per row of 16 lanes) held in `d`; the row's sums go to
 // LDS slot `slot` (a negative slot belongs to a stand-in row and is dropped).
-template <int NK, bool NYQ>
+template <int MODE, int NK, bool NYQ>
 __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int l,
-                                             float lc1, float ls1, float lc2, float ls2, bd_spec_slot *slots)
+                                             float lc1, float ls1, float lc2, float ls2, bd_spec_slots *slots)
 {
     float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
     int dc = 0, ny = 0;
@@ -110,7 +122,8 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
         }
     }
     // (a - i b) * (cos - i sin): apply the per-lane offset 8 l, then reduce the row
-    bd_spec_slot r;
+    bd_spec_sums r;
+    bd_spec_misc rm;
     r.re1 = r.im1 = r.re2 = r.im2 = 0.f;
     if (NK >= 1) {
         r.re1 = bd_row_sum(a1 * lc1 - b1 * ls1);
@@ -120,10 +133,10 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
         r.re2 = bd_row_sum(a2 * lc2 - b2 * ls2);
         r.im2 = bd_row_sum(a2 * ls2 + b2 * lc2);
     }
-    r.dc = bd_row_sum(dc);
-    r.ny = NYQ ? bd_row_sum(ny) : 0;
-    r.amax = bd_row_max(amax);
-    r.pad = 0.f;
+    rm.dc = bd_row_sum(dc);
+    rm.ny = NYQ ? bd_row_sum(ny) : 0;
+    rm.amax = bd_row_max(amax);
+    rm.pad = 0.f;
     // Lane 0 of each row parks the row's sums.  Combining neighbouring half-blocks into
     // callbacks, magnitudes, scaling and the decision happen once per run with all lanes busy
     // (bd_spec_finish) instead of on four lanes in every iteration.
@@ -132,22 +145,28 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
     // one add that reads its operand through the lane rotation.)
     if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1));
     if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2));
-    if (NYQ) asm volatile("" :: "v"(r.ny));
-    asm volatile("" :: "v"(r.dc), "v"(r.amax));
-    if (l == 0 && slot >= 0) slots[slot] = r;
+    if (NYQ) asm volatile("" :: "v"(rm.ny));
+    asm volatile("" :: "v"(rm.dc), "v"(rm.amax));
+    if (l == 0 && slot >= 0) {
+        const int e = bd_spec_entry<MODE>(slot);
+        slots->sums[e] = r;
+        slots->misc[e] = rm;
+    }
 }
 
 // Callback i of the run from the sums of its two half-blocks: X_k = P_k(prev) + (-1)^k P_k(cur).
 template <int MODE, int NK, bool NYQ>
-__device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_spec_slot *slots, unsigned i,
+__device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_spec_slots *slots, unsigned i,
                                                float *value_out, uint8_t *flag_out)
 {
-    const bd_spec_slot p = slots[MODE == 0 ? i : 2 * i];
-    const bd_spec_slot c = slots[MODE == 0 ? i + 1 : 2 * i + 1];
-    const float x_dc = (float)(p.dc + c.dc);
+    const int ep = bd_spec_entry<MODE>(MODE == 0 ? (int)i : 2 * (int)i);
+    const int ec = bd_spec_entry<MODE>(MODE == 0 ? (int)i + 1 : 2 * (int)i + 1);
+    const bd_spec_sums p = slots->sums[ep], c = slots->sums[ec];
+    const bd_spec_misc pm = slots->misc[ep], cm = slots->misc[ec];
+    const float x_dc = (float)(pm.dc + cm.dc);
     float m0 = fabsf(x_dc);
     if (NYQ) {
-        const float x_ny = (float)(p.ny + c.ny);
+        const float x_ny = (float)(pm.ny + cm.ny);
         m0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
     }
     float best = a.include_dc ? m0 : 0.f;
@@ -162,7 +181,7 @@ __device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_s
     const float value = (a.divisor == 0.f) ? best : best / a.divisor;
     // the amplitude gate looks at the callback's own samples (spectrum.rs:77): one half-block
     // for 512-sample callbacks, both for 1024
-    const float wmax = fminf(MODE == 0 ? c.amax : fmaxf(c.amax, p.amax), 32767.f);
+    const float wmax = fminf(MODE == 0 ? cm.amax : fmaxf(cm.amax, pm.amax), 32767.f);
     const bool gate = wmax >= (float)a.min_amp;
     *value_out = value;
     *flag_out = (gate && (value > a.threshold)) ? 1 : 0;
@@ -195,15 +214,17 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
 
     // slot 0 of a hop-512 run is the half-block before the run; the others follow
-    __shared__ bd_spec_slot lds_slots[4][BD_SPEC_MAX_RUN + 4];
-    bd_spec_slot *slots = lds_slots[wave];
+    __shared__ bd_spec_slots lds_slots[4];
+    bd_spec_slots *slots = &lds_slots[wave];
     constexpr int SLOT0 = MODE == 0 ? 1 : 0;
     if (MODE == 0 && hb0 == 0 && lane == 0) {
         // before the stream the ring holds zeros (spectrum.rs:50-51)
-        bd_spec_slot z;
-        z.re1 = z.im1 = z.re2 = z.im2 = z.amax = z.pad = 0.f;
-        z.dc = z.ny = 0;
-        slots[0] = z;
+        bd_spec_sums z;
+        bd_spec_misc zm;
+        z.re1 = z.im1 = z.re2 = z.im2 = zm.amax = zm.pad = 0.f;
+        zm.dc = zm.ny = 0;
+        slots->sums[0] = z;
+        slots->misc[0] = zm;
     }
 
     // Two register buffers, each filled one iteration ahead of its use.  Loads
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         bd_load_hb(d, sp, hb, l);
     };
     auto run = [&](const uint4 (&d)[4], int it) {
-        bd_spec_iter<NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
+        bd_spec_iter<MODE, NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
     };
     // Steady state: every load is issued one iteration ahead of its use.  The
     // last one or two iterations are peeled so that nothing is loaded twice.
@@ -248,12 +269,35 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const uint64_t o0 = s * a.out_stride + cb0;
     __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, n_res);
     __amdgpu_buffer_rsrc_t rv = bd_out_rsrc(a.values ? a.values + o0 : nullptr, a.values ? n_res * 4u : 0u);
+#ifdef BD_STORE_EXPERIMENT
+    // Experiment build (tools/exp_store.py): the same results through other store policies, or with
+    // one of the two outputs dropped or redirected, to find what the result stores cost.
+    if (a.store_mode == 7) rf = bd_out_rsrc(nullptr, 0);                       // no decisions either
+    if (a.store_mode == 8 && a.values)                                          // values into one 1 MiB window
+        rv = bd_out_rsrc(a.values + (o0 & 0x3ffffull & ~127ull), n_res * 4u);
+    for (unsigned i = lane; i < n_res_run; i += 64) {
+        float value; uint8_t flag;
+        bd_spec_finish<MODE, NK, NYQ>(a, slots, i, &value, &flag);
+        bd_store_stream_u8(rf, i, flag);
+        const unsigned vb = __builtin_bit_cast(unsigned, value);
+        switch (a.store_mode) {
+        case 1: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 0); break;
+        case 2: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 2); break;
+        case 3: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 16); break;
+        case 4: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 19); break;
+        case 5: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 17); break;
+        case 6: __builtin_amdgcn_raw_buffer_store_b32(vb, rv, i * 4u, 0, 1); break;
+        default: bd_store_stream_f32(rv, i * 4u, value); break;
+        }
+    }
+#else
     for (unsigned i = lane; i < n_res_run; i += 64) {
         float value; uint8_t flag;
         bd_spec_finish<MODE, NK, NYQ>(a, slots, i, &value, &flag);
         bd_store_stream_u8(rf, i, flag);
         bd_store_stream_f32(rv, i * 4u, value);   // a zero-sized descriptor drops the store
     }
+#endif
 }
 
 // ---- generic path ---------------------------------------------------------
@@ -583,8 +627,9 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0);
     const bool fast_len = callback_len == 512 || callback_len == 1024;
     const bool fast_bins = plan.last_bin <= 2;
-    // BD_SPEC_FORCE_GRANULE=1 routes 512 / 1024 to the granule kernel as well (A/B experiments)
-    if (aligned && fast_len && fast_bins && !getenv("BD_SPEC_FORCE_GRANULE")) {
+    const bd_tuning &tune = bd_tuning_get();   // experiment switches, read from the environment once
+    // spec_force_granule routes 512 / 1024 to the granule kernel as well (A/B experiments)
+    if (aligned && fast_len && fast_bins && !tune.spec_force_granule) {
         bd_spec_args a;
         a.samples = samples; a.values = values; a.flags = flags;
         a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;
@@ -595,22 +640,20 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         // start; short streams still need enough wavefronts to fill 256 CUs.
         uint32_t run = 128;
         while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
-        const char *run_env = getenv("BD_SPEC_RUN"); // tuning knob, read at every launch
-        const int run_override = run_env ? atoi(run_env) : 0;
+        const int run_override = tune.spec_run;
         if (run_override >= 8 && run_override % 8 == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
         a.run_hbs = run;
         a.runs_per_stream = (uint32_t)((n_hb + run - 1) / run);
         a.n_tasks = n_streams * a.runs_per_stream;
         a.min_amp = plan.min_amp; a.include_dc = plan.first_bin == 0;
         a.divisor = plan.divisor; a.threshold = plan.threshold;
+        a.store_mode = (uint32_t)tune.spec_store;
         const uint64_t grid64 = (a.n_tasks + 3) / 4;
         dim3 grid_dims;
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
         const dim3 grid = grid_dims;
-        // unused dynamic LDS caps the workgroups resident per CU (tuning knob, read at every launch)
-        const char *pad_env = getenv("BD_SPEC_LDS_PAD");
-        unsigned lds_pad = pad_env ? (unsigned)atoi(pad_env) : 0;
-        if (lds_pad > 150000) lds_pad = 150000;
+        // unused dynamic LDS caps the workgroups resident per CU (experiment switch)
+        const unsigned lds_pad = tune.spec_lds_pad;
         const int nk = plan.last_bin; // bins 1..last_bin
         const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
         if (callback_len == 512) {
@@ -639,15 +682,15 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // stays on granules of 32 at 4.6)
     const uint32_t gran = bd_spectrum_granule_size(callback_len);
     const bool split_first = (callback_len % 64 != 0 || callback_len > 512) && !(callback_len < 129 && gran >= 32) &&
-                             bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT");
+                             bd_spectrum_split_applies(plan, callback_len) && !tune.spec_no_split;
     if (gran != 0 && plan.last_bin <= bd_spectrum_granule_max_bins(gran) && !split_first &&
-        !getenv("BD_SPEC_NO_GRANULE") && !(callback_len % 64 != 0 && getenv("BD_SPEC_NO_SMALL_GRANULE")))
+        !tune.spec_no_granule && !(callback_len % 64 != 0 && tune.spec_no_small_granule))
         // (granules of 63 samples for 63 q: 441, 882 below the window kernel's HBM-bound range)
         return bd_launch_spectrum_granule(plan, samples, n_streams, n_samples, stride, callback_len, values, flags,
                                           out_stride, st);
     // everything else with at most 12 kept bins: the window kernel; the callbacks whose ring starts
     // before the stream does (zeros, spectrum.rs:50-51) take the generic kernel
-    const bool window_path = plan.last_bin <= BD_GR_MAX_BINS && !getenv("BD_SPEC_NO_GRANULE");
+    const bool window_path = plan.last_bin <= BD_GR_MAX_BINS && !tune.spec_no_granule;
     uint64_t n_generic = n_cb;
     if (window_path) {
         const uint64_t j_min = (BD_RING_LEN + callback_len - 1) / callback_len - 1; // callbacks with (j + 1) L < 1024
@@ -670,7 +713,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // 129 .. 767 samples off the 64-sample grid (the reference's Linux callbacks, 500 .. 540, among them): the split kernel, which
     // multiplies every sample by its twiddles once; the last callback of a stream goes to the generic kernel
     // (the split kernel's 16-byte loads may reach a few samples past a callback's end)
-    if (window_path && bd_spectrum_split_applies(plan, callback_len) && !getenv("BD_SPEC_NO_SPLIT")) {
+    if (window_path && bd_spectrum_split_applies(plan, callback_len) && !tune.spec_no_split) {
         int rc = launch_generic(n_cb - 1, 1);
         if (rc != BD_OK || n_cb == 1) return rc;
         return bd_launch_spectrum_split(plan, samples, n_streams, n_cb - 1, stride, callback_len, values, flags, out_stride, st);

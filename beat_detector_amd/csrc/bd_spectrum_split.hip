@@ -569,10 +569,10 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     const bool narrow = callback_len < 384, narrow4 = callback_len < 128;
     const int group = narrow4 ? 32 : (narrow ? 64 : 128);
     const int pstar = (int)(a.head_len / group), pl = (int)(callback_len / group);
-    const bool rem = !narrow && (int)callback_len - group * pl <= BD_SPLIT_REM_MAX && !getenv("BD_SPLIT_NO_REM");
+    const bool rem = !narrow && (int)callback_len - group * pl <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
     // the narrow variants always stage (a row of 4 or 8 lanes loads only 64 or 128 contiguous bytes per
     // instruction: 100 samples 3.0 -> 3.5 TB/s, 300 4.6 -> 5.2 with the staged copy's whole-line loads)
-    const bool staged = narrow || (callback_len % 4 != 0 && !getenv("BD_SPLIT_NO_STAGE"));
+    const bool staged = narrow || (callback_len % 4 != 0 && !bd_tuning_get().split_no_stage);
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }

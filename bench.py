@@ -12,13 +12,24 @@ the data path); the reported value is the audio-seconds all ranks analysed per
 wall-second, timed between barriers, maximum over ranks.
 
 With --gpus N > 1 and no launcher environment (RANK / WORLD_SIZE unset) the
-script starts its own N rank processes, one per GPU, before it touches the GPU;
-under `python -m torch.distributed.run` it is a rank as before.
+script starts its own N rank processes, one per GPU, before it touches the GPU
+(with a wall limit: --launch-timeout); under `python -m torch.distributed.run`
+it is a rank as before.  The process group only carries barriers, the
+max-over-ranks of the timings and the per-rank report (gloo over loopback by
+default, the other backend as fallback; waits bounded by --group-timeout).
 
-Rank 0 prints one JSON line.  `roofline` prices the dominant kernel against HBM
-bandwidth using HIP events recorded inside the timed region; `cpu_baseline` is
+Rank 0 prints one JSON line.  `value` / `roofline` time the launch that writes
+every output of the batched entry (per callback the decision and the detection
+value: 5 B); `value_decisions_only` / `roofline_decisions_only` time, over the
+same number of steps, the launch that writes what the reference's strategies
+return (decisions -> beats, 1 B per callback).  Both price the dominant kernel
+against HBM bandwidth using HIP events recorded inside their timed region.
+`ranks` lists, per rank, the GPU it ran on (index, name, PCI id / UUID), its
+shard and its own timings; `backend` and `ranks_seen` say how they were
+gathered.  `cpu_baseline` is
 the CPU restatement of the reference (oracle/) timed on this host's cores on a
-bounded sample of the same streams (N = 1 only); `also` holds short
+bounded sample of the same streams (N = 1 only), compared with the GPU's beat
+lists stream by stream; `also` holds short
 measurements of the other workloads (LPF, the extension analyses, one GPU's
 share of the 131,072-track job through the chunked executor, live latency),
 taken after and outside the headline's timed region.
@@ -90,8 +101,10 @@ METRIC = {"Spectrum": "1024-pt STFT", "LPF": "lowpass windows", "Biquad": "carri
 # --------------------------------------------------------------------------------------------
 # launcher: --gpus N without a launcher environment
 # --------------------------------------------------------------------------------------------
-def self_launch(n: int) -> int:
-    """Starts the N ranks as child processes (this process never touches the GPU) and waits."""
+def self_launch(n: int, wall_limit_s: float) -> int:
+    """Starts the N ranks as child processes (this process never touches the GPU) and waits for them,
+    at most `wall_limit_s` seconds: a rank that fails, or the limit, ends every other rank, and the
+    launcher exits non-zero instead of hanging."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -101,8 +114,20 @@ def self_launch(n: int) -> int:
                    MASTER_PORT=str(port), BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def end(pending):
+        for q in pending:
+            q.terminate()
+        t_end = time.monotonic() + 10
+        for q in pending:
+            try:
+                q.wait(max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+
     rc = 0
     pending = list(procs)
+    deadline = time.monotonic() + wall_limit_s
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -111,30 +136,93 @@ def self_launch(n: int) -> int:
             pending.remove(p)
             if code != 0 and rc == 0:
                 rc = code
-                for q in pending:  # a rank failed: the others would wait at a barrier for ever
-                    q.terminate()
+                print(f"bench.py: rank {procs.index(p)} exited with {code}; ending the other ranks", file=sys.stderr)
+                end(pending)   # a rank failed: the others would wait at a barrier until its timeout
+                pending = []
+        if pending and time.monotonic() > deadline:
+            print(f"bench.py: {len(pending)} of {n} ranks still running after {wall_limit_s:.0f} s "
+                  "(--launch-timeout); ending them", file=sys.stderr)
+            end(pending)
+            return 124
         time.sleep(0.05)
     return rc
 
 
-def rehearse_launch(args) -> None:
+def init_group(args, rank: int, world: int, device=None):
+    """The process group of a multi-rank run.  The data path has no collective (streams are independent:
+    one AnalysisState and one ring per detector, src/strategies/mod.rs:39-56 of the reference), so the group
+    only carries the barriers around the timed region, the max-over-ranks of the timings and the per-rank
+    report: gloo over loopback by default; whichever of gloo / nccl is not the first choice is the fallback
+    when the first fails to initialise.  Every wait is bounded by --group-timeout.
+    Returns (torch.distributed, backend used, device for reduction tensors, notes)."""
+    import datetime
     import torch
     import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost") and os.path.isdir("/sys/class/net/lo"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the host name of a container may not resolve
+    timeout = datetime.timedelta(seconds=args.group_timeout)
+    order = [args.backend] + [b for b in ("gloo", "nccl") if b != args.backend]
+    notes = []
+    for backend in order:
+        try:
+            if backend == "nccl":
+                if device is None:
+                    raise RuntimeError("nccl (RCCL) needs a GPU per rank; this rank has none")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=timeout)
+                t = torch.ones(1, device=device)
+                dist.all_reduce(t)                          # RCCL builds its communicator on first use
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
+                t = torch.ones(1)
+                dist.all_reduce(t)
+            if int(t[0]) != world:
+                raise RuntimeError(f"first all-reduce over {backend} saw {int(t[0])} of {world} ranks")
+            return dist, backend, (device if backend == "nccl" else torch.device("cpu")), notes
+        except Exception as e:  # noqa: BLE001 - whatever the backend raises, the other one is tried
+            notes.append(f"{backend}: {type(e).__name__}: {str(e).splitlines()[0] if str(e) else ''}")
+            print(f"bench.py: rank {rank}: process group over {backend} failed ({notes[-1]})", file=sys.stderr)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:  # noqa: BLE001
+                pass
+    raise SystemExit("bench.py: no process-group backend could be initialised: " + "; ".join(notes))
+
+
+def gather_ranks(dist, world: int, mine: dict):
+    """Every rank's report, in rank order (rank 0 prints them as `ranks`)."""
+    if dist is None:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def rehearse_launch(args) -> None:
+    """No GPU work: the ranks join the group and exchange their reports as a real run does."""
     from beat_detector_amd import sharding
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    t = torch.tensor([1, rank, int(os.environ.get("LOCAL_RANK", "0"))], dtype=torch.int64)
+    dist, backend, notes = None, None, []
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        dist.all_reduce(t)
+        dist, backend, _, notes = init_group(args, rank, world, None)
+    if args.rehearse_sleep:
+        time.sleep(args.rehearse_sleep)
+    streams = WORKLOADS[args.workload][2]
+    first, last = sharding.shard_range(world * streams, rank, world)
+    ranks = gather_ranks(dist, world, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                                       "pid": os.getpid(), "host": socket.gethostname(), "device_index": None,
+                                       "device_name": None, "device_id": None, "shard": [first, last],
+                                       "kernel_ms": None})
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        streams = WORKLOADS[args.workload][2]
-        print(json.dumps({"rehearsal": "launch", "ranks": int(t[0]), "rank_sum": int(t[1]), "local_rank_sum": int(t[2]),
-                          "shards": [list(sharding.shard_range(world * streams, r, world)) for r in range(world)]}),
-              flush=True)
+        print(json.dumps({"rehearsal": "launch", "backend": backend, "backend_notes": notes, "ranks_seen": len(ranks), "ranks": ranks,
+                          "shards": [r["shard"] for r in ranks]}), flush=True)
 
 
 class Ctx:
@@ -146,27 +234,52 @@ class Ctx:
         self.torch, self.bd, self.args = torch, bd, args
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
-        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != max(args.gpus, 1):
             raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {self.world}")
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (there is no CPU path)")
-        if args.share_device:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        self.dev = torch.device("cuda", local_rank)
-        self.dist = None
+        index = 0 if args.share_device else self.local_rank
+        if index >= torch.cuda.device_count():
+            raise SystemExit(f"rank {self.rank}: local rank {self.local_rank} has no GPU of its own "
+                             f"({torch.cuda.device_count()} visible); --share-device runs every rank on GPU 0")
+        torch.cuda.set_device(index)
+        self.dev = torch.device("cuda", index)
+        self.dist, self.backend, self.backend_notes = None, None, []
+        self.red_dev = torch.device("cpu")
         if self.world > 1:
-            import torch.distributed as dist
-            self.dist = dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
-            else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-        self.red_dev = self.dev if args.backend == "nccl" else torch.device("cpu")
+            self.dist, self.backend, self.red_dev, self.backend_notes = init_group(args, self.rank, self.world, self.dev)
         self.lib = bd.lib()
         self.st = torch.cuda.current_stream().cuda_stream
+
+    def report(self, shard, kernel_ms, ms_per_step):
+        """What this rank contributes to the `ranks` list: which physical GPU it ran on, its shard, its timings."""
+        torch = self.torch
+        props = torch.cuda.get_device_properties(self.dev)
+        ident = None
+        if hasattr(props, "pci_bus_id"):
+            ident = "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+        uuid = str(getattr(props, "uuid", "")) or None
+        try:
+            name = self.bd.device_name(self.dev.index)[0]      # bd_device_name: what the library itself runs on
+        except Exception:  # noqa: BLE001
+            name = props.name
+        return {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid(), "host": socket.gethostname(),
+                "device_index": self.dev.index, "device_name": name, "device_id": ident, "device_uuid": uuid,
+                "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES"),
+                "shard": [int(shard[0]), int(shard[1])], "kernel_ms": kernel_ms, "ms_per_step": ms_per_step}
+
+    def ranks(self, shard, kernel_ms, ms_per_step):
+        """Gathers every rank's report; two ranks on one physical GPU are an error unless --share-device."""
+        reports = gather_ranks(self.dist, self.world, self.report(shard, kernel_ms, ms_per_step))
+        seen = {}
+        for r in reports:
+            key = (r["host"], r.get("visible_devices"), r["device_uuid"] or r["device_id"] or r["device_index"])
+            if key in seen and not self.args.share_device:
+                raise SystemExit(f"bench.py: ranks {seen[key]} and {r['rank']} both ran on GPU {key[2]} of {key[0]}: "
+                                 "a multi-GPU measurement needs one GPU per rank (--share-device is for rehearsals)")
+            seen[key] = r["rank"]
+        return reports
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -192,16 +305,27 @@ class Ctx:
         if rc != 0:
             raise RuntimeError(self.lib.bd_last_error().decode())
 
-    def first_stream(self, streams):
+    def shard(self, streams):
+        """[first, last) of this rank's streams: weak scaling, `streams` per GPU."""
         from beat_detector_amd import sharding
-        return sharding.shard_range(self.world * streams, self.rank, self.world)[0]
+        return sharding.shard_range(self.world * streams, self.rank, self.world)
+
+    def first_stream(self, streams):
+        return self.shard(streams)[0]
 
 
 # --------------------------------------------------------------------------------------------
 # a workload whose samples are resident in HBM
 # --------------------------------------------------------------------------------------------
-def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values_too=True):
-    """Measures one workload; returns (result dict, state kept for the CPU baseline)."""
+def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, outputs="both"):
+    """Measures one workload; returns (result dict, state kept for the CPU baseline).
+
+    The two strategies are timed twice over the same `steps`, each between barriers: once with every
+    output of the batched entry written (per callback the decision, 1 B, and the detection value, 4 B:
+    the headline, `value` / `roofline`), once with the decisions alone (`value_decisions_only` /
+    `roofline_decisions_only`: what the reference's strategies return, Strategy::is_beat -> Option<BeatInfo>,
+    src/lib.rs:72-78, has no value in it).  `outputs` = "values" or "decisions" runs one of the two only
+    (profiling runs: every launch of the dominant kernel is then of one kind)."""
     import ctypes
     torch, bd, L_ = ctx.torch, ctx.bd, ctx.lib
     kind_name, L, d_streams, d_seconds, desc = WORKLOADS[workload]
@@ -214,7 +338,8 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values
     n = sr * seconds
     stride = (n + 63) & ~63  # rows start on 128-byte boundaries
     # weak scaling: `streams` per GPU, rank r owns the r-th contiguous shard of world * streams
-    first_stream = ctx.first_stream(streams)
+    shard = ctx.shard(streams)
+    first_stream = shard[0]
 
     samples = torch.empty((streams, stride), dtype=torch.int16, device=dev)
     bd.synth_fill(samples, n_samples=n, first_stream=first_stream, seed=SEED, sampling_rate=sr)
@@ -235,9 +360,9 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values
     ms = torch.zeros((streams, max_beats), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    decisions_only = False
+    two_modes = not (onset or biquad)        # the value rows are optional for the two strategies only
     if onset:
-        def stage1():  # `values` holds the flux rows, `flags` the band-energy rows
+        def stage1(with_values=True):  # `values` holds the flux rows, `flags` the band-energy rows
             ctx.check(L_.bd_onset_stft(sr, ctypes.byref(oparams), samples.data_ptr(), streams, n, stride,
                                        values.data_ptr(), flags.data_ptr(), out_stride, st))
 
@@ -249,17 +374,11 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values
             bq_params = bd.BiquadParams.default(window_len=L)
             bq_design = bd.biquad_design(sr, bq_params.cutoff_hz, bq_params.q_factor)
 
-            def stage1():
+            def stage1(with_values=True):
                 ctx.check(L_.bd_biquad_envelope(sr, ctypes.byref(bq_params), ctypes.byref(bq_design), samples.data_ptr(),
                                                 streams, n, stride, values.data_ptr(), flags.data_ptr(), out_stride, st))
         else:
-            # The reference's strategies return beats only (Strategy::is_beat -> Option<BeatInfo>, src/lib.rs:72-78); the per-callback
-            # detection value is an optional output of this library, kept for parity checks.  The timed
-            # region asks for what the reference produces: decisions and beat lists.  The launch with
-            # values is timed next to it (`kernel_ms_with_values`); BENCH_WITH_VALUES=1 makes it the timed one.
-            decisions_only = not os.environ.get("BENCH_WITH_VALUES")
-
-            def stage1(with_values=not decisions_only):
+            def stage1(with_values=True):
                 ctx.check(L_.bd_batch_candidates(kind.value, sr, None, samples.data_ptr(), streams, n, stride, L,
                                                  values.data_ptr() if with_values else None, flags.data_ptr(), out_stride, st))
 
@@ -267,60 +386,70 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values
             ctx.check(L_.bd_refractory(sr, None, L, flags.data_ptr(), out_stride, streams, n_cb, count.data_ptr(),
                                        idx.data_ptr(), ms.data_ptr(), max_beats, st))
 
-    stage1()
+    def timed(with_values):
+        """`warmup` untimed steps, then exactly `steps` steps between barriers; (wall seconds, dominant
+        kernel ms, second pass ms) with HIP events on the launch stream inside the timed region."""
+        for _ in range(warmup):
+            stage1(with_values)
+            stage2()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        ctx.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            stage1(with_values)           # dominant kernel
+            ev[k][1].record()
+            stage2()                      # refractory pass / peak picking
+            ev[k][2].record()
+        ctx.barrier()
+        elapsed = time.perf_counter() - t0
+        if os.environ.get("BENCH_VERBOSE"):
+            print("per-step kernel ms (values written: %s):" % with_values,
+                  [round(e[0].elapsed_time(e[1]), 3) for e in ev], file=sys.stderr)
+        k1 = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+        k2 = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+        elapsed_max, k1_max = ctx.max_over_ranks(elapsed, k1)
+        return {"elapsed": elapsed_max, "k1_ms": k1_max, "k2_ms": k2, "own_k1_ms": k1, "own_ms_per_step": elapsed / steps * 1e3}
+
+    stage1(outputs != "decisions")
     launched = bd.last_kernel_name()      # the kernel the entry point routed this workload to
     stage2()
-    for _ in range(warmup):
-        stage1()
-        stage2()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
-    ctx.barrier()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        ev[k][0].record()
-        stage1()                      # dominant kernel
-        ev[k][1].record()
-        stage2()                      # refractory pass / peak picking
-        ev[k][2].record()
-    ctx.barrier()
-    elapsed = time.perf_counter() - t0
-    if os.environ.get("BENCH_VERBOSE"):
-        print("per-step kernel ms:", [round(e[0].elapsed_time(e[1]), 3) for e in ev], file=sys.stderr)
-    k1_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
-    k2_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
-    k1_values_ms = None
-    if decisions_only and with_values_too:
-        # the same launch with the detection values written as well (they feed the parity check below)
-        evv = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(3)]
-        for e in evv:
-            e[0].record()
-            stage1(True)
-            e[1].record()
-        torch.cuda.synchronize()
-        k1_values_ms = sum(e[0].elapsed_time(e[1]) for e in evv) / len(evv)
+    main_with_values = outputs != "decisions" or not two_modes
+    t_main = timed(main_with_values)
+    t_dec = timed(False) if (two_modes and outputs == "both") else None
+    if two_modes and outputs == "both":
+        stage1(True)                      # the value rows feed the comparison with the CPU baseline
+    torch.cuda.synchronize()
     kernel_name = launched or {"Spectrum": "bd_spectrum_band_kernel", "LPF": "bd_lpf_window_kernel",
                                "Onset": "bd_stft_flux_kernel", "Biquad": "bd_biquad_env_kernel"}[kind_name]
     total_beats = ctx.sum_over_ranks(int(count.sum().item()))
-    elapsed, k1_ms = ctx.max_over_ranks(elapsed, k1_ms)
-
     world = ctx.world
-    value = world * streams * (n / sr) * steps / elapsed
-    # algorithmic bytes of one launch of the dominant kernel: every sample that
-    # belongs to a callback read once (2 B) + per callback the decision (1 B) and,
-    # where the launch writes it, the detection value (4 B)
-    alg_bytes = streams * (n_cb * L * 2 + n_cb * (1 if decisions_only else 5))
-    if onset:  # every sample of a complete frame once + flux and band energy (8 B) per frame
-        alg_bytes = streams * (((n_cb - 1) * L + nfft) * 2 + n_cb * 8) if n_cb else 0
-    achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
-    traffic, traffic_source = _pmc_traffic(workload, streams, seconds)
+
+    # algorithmic bytes of one launch of the dominant kernel: every sample that belongs to a callback
+    # read once (2 B) + per callback the decision (1 B) and, where the launch writes it, the value (4 B)
+    def alg_bytes_of(with_values):
+        if onset:  # every sample of a complete frame once + flux and band energy (8 B) per frame
+            return streams * (((n_cb - 1) * L + nfft) * 2 + n_cb * 8) if n_cb else 0
+        return streams * (n_cb * L * 2 + n_cb * (5 if with_values else 1))
+
+    def roofline_of(t, with_values):
+        alg = alg_bytes_of(with_values)
+        achieved = alg / (t["k1_ms"] * 1e-3) / 1e9
+        traffic, traffic_source = _pmc_traffic(workload, streams, seconds, with_values or not two_modes)
+        return {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": alg, "kernel_ms": t["k1_ms"], "refractory_ms": t["k2_ms"],
+                "outputs_written": ("decisions + detection values" if with_values else "decisions") if two_modes
+                                   else "every output of the entry point"}
+
     result = {
         "metric": "audio-sec analysed/sec (node), " + ("%d-pt STFT" % nfft if onset else METRIC[kind_name]),
-        "value": value,
+        "value": world * streams * (n / sr) * steps / t_main["elapsed"],
         "unit": "audio-sec/s",
         "n_gpus": world,
         "steps": steps,
         "warmup": warmup,
-        "ms_per_step": elapsed / steps * 1e3,
+        "ms_per_step": t_main["elapsed"] / steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -337,31 +466,28 @@ def run_resident(ctx, workload, steps, warmup, streams=0, seconds=0, with_values
             "seed": SEED,
             "parallelism": f"stream-sharded x{world}, no collectives",
             "beats_found": total_beats,
-            "outputs": ("decisions + beat lists (what the reference's strategies return); detection values not written"
-                        if decisions_only else "decisions + detection values + beat lists"),
+            "outputs": ("decisions + detection values + beat lists" if main_with_values
+                        else "decisions + beat lists (what the reference's strategies return); detection values not written"),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": kernel_name,
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic,
-            "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": k1_ms,
-            "refractory_ms": k2_ms,
-        },
+        "roofline": roofline_of(t_main, main_with_values),
     }
-    if k1_values_ms is not None:
-        result["roofline"]["kernel_ms_with_values"] = k1_values_ms
+    if t_dec is not None:
+        result["value_decisions_only"] = world * streams * (n / sr) * steps / t_dec["elapsed"]
+        result["ms_per_step_decisions_only"] = t_dec["elapsed"] / steps * 1e3
+        result["roofline_decisions_only"] = roofline_of(t_dec, False)
     if onset:
         result["roofline"]["note"] = ("this kernel is limited by f32 VALU issue (a 2048-point FFT per 1024 new samples), "
                                       "not by HBM; the HBM fraction is reported for comparison with the other workloads")
-        result["roofline"]["valu"] = _valu_roofline(streams, n_cb, nfft, k1_ms)
+        result["roofline"]["valu"] = _valu_roofline(streams, n_cb, nfft, t_main["k1_ms"])
+    # which GPU every rank ran on, its shard and its own timings (the driver can check N distinct devices)
+    result["backend"] = ctx.backend
+    result["ranks"] = ctx.ranks(shard, t_main["own_k1_ms"], t_main["own_ms_per_step"])
+    result["ranks_seen"] = len(result["ranks"])
+    if ctx.backend_notes:
+        result["backend_notes"] = ctx.backend_notes
     state = dict(flux_power=1 if workload.endswith("_power") else 0, kind_name=kind_name, samples=samples, values=values, flags=flags, count=count, idx=idx, ms=ms, n=n, L=L,
-                 sr=sr, nfft=nfft, streams=streams, out_stride=out_stride)
+                 sr=sr, nfft=nfft, streams=streams, out_stride=out_stride, max_beats=max_beats,
+                 has_values=main_with_values or t_dec is not None)
     return result, state
 
 
@@ -374,14 +500,15 @@ def _valu_roofline(streams, n_frames, nfft, k_ms):
             "frac": flops / (k_ms * 1e-3) / 1e12 / peak_tflops, "flops_per_frame": 2.5 * nfft * (nfft.bit_length() - 1)}
 
 
-def _pmc_traffic(workload, streams, seconds):
+def _pmc_traffic(workload, streams, seconds, with_values=True):
     """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The figure is not
-    measured in this run: it is replayed from the committed rocprofv3 PMC passes of this same command."""
+    measured in this run: it is replayed from the committed rocprofv3 PMC passes of this same command
+    (`--outputs values` for the launch that writes the detection values, `--outputs decisions` for the other)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        e = t.get(workload)
+        e = t.get(workload if with_values else workload + "_decisions")
         if e and e.get("streams") == streams and e.get("seconds") == seconds:
             return e.get("hbm_bytes_per_launch"), ("committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                                    "(%s), not measured in this run" % e.get("source", "profiles/"))
@@ -424,9 +551,29 @@ def run_chunked_onset(ctx, steps, warmup, tracks=0, seconds=0, chunk=0):
     ctx.barrier()
     elapsed = time.perf_counter() - t0
     main_ms, post_ms = ex.last_timing()            # the chunks of the last timed pass
-    k_ms = sum(main_ms) / max(len(main_ms), 1)
+    own_k_ms = k_ms = sum(main_ms) / max(len(main_ms), 1)
+    own_ms_per_step = elapsed / steps * 1e3
     total = ctx.sum_over_ranks(int(count.sum().item()))
     elapsed, k_ms = ctx.max_over_ranks(elapsed, k_ms)
+    # The same passes with a source that enqueues nothing (the two chunk buffers keep the samples of the
+    # chunks synthesised last): the analysis of every chunk and the executor's hand-over events without
+    # the synthetic source's cost.  The onsets of these passes are those of the stale samples and are not
+    # looked at.
+    scratch_count = torch.zeros_like(count)
+
+    def null_step():
+        ex.onset(SR, tracks, scratch_count, frame, ms, params=p, source=lambda *a: 0)
+
+    null_step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        null_step()
+    ctx.barrier()
+    elapsed_null = time.perf_counter() - t0
+    null_main_ms, _ = ex.last_timing()
+    k_ms_null = sum(null_main_ms) / max(len(null_main_ms), 1)
+    elapsed_null, k_ms_null = ctx.max_over_ranks(elapsed_null, k_ms_null)
     dev_bytes = ex.device_bytes()
     n_chunks = (tracks + chunk - 1) // chunk
     alg_bytes = chunk * (((n_frames - 1) * hop + nfft) * 2 + n_frames * 4) if n_frames else 0   # per launch = per chunk
@@ -439,23 +586,33 @@ def run_chunked_onset(ctx, steps, warmup, tracks=0, seconds=0, chunk=0):
         "n_gpus": ctx.world,
         "steps": steps,
         "ms_per_step": elapsed / steps * 1e3,
+        "value_excluding_synthesis": ctx.world * tracks * (n / SR) * steps / elapsed_null,
+        "ms_per_step_excluding_synthesis": elapsed_null / steps * 1e3,
         "scaling": "weak",
         "config": {"workload": desc, "tracks_per_gpu": tracks, "seconds_per_track": seconds, "chunk_tracks": chunk,
                    "chunks_per_pass": n_chunks, "frames_per_track": n_frames, "device_bytes_held": dev_bytes,
                    "samples_bytes_per_pass": tracks * n * 2, "onsets_found": total, "seed": SEED,
                    "timed_region": "whole pass: on-device synthesis of every chunk (side stream, overlapped) + STFT/flux + "
-                                   "peak picking; the samples of a pass never exist at once"},
+                                   "peak picking; the samples of a pass never exist at once",
+                   "timed_region_excluding_synthesis": "the same pass with a source that enqueues nothing (the chunk "
+                                                       "buffers keep the last synthesised chunks): analysis of every "
+                                                       "chunk + hand-over events, no generator"},
         "roofline": {"bound": "hbm", "kernel": "bd_stft_flux_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                      "peak_picking_ms": sum(post_ms) / max(len(post_ms), 1),
                      "kernel_ms_per_chunk": [round(x, 3) for x in main_ms],
+                     "kernel_ms_excluding_synthesis": k_ms_null,
+                     "frac_excluding_synthesis": (alg_bytes / (k_ms_null * 1e-3) / 1e9 / HBM_PEAK_GBPS) if k_ms_null else None,
                      "note": "VALU-issue bound (a 2048-point f32 FFT per 1024 new samples); launches overlap the synthesis "
                              "of the next chunk",
                      "valu": _valu_roofline(chunk, n_frames, nfft, k_ms) if k_ms else None},
     }
+    result["backend"] = ctx.backend
+    result["ranks"] = ctx.ranks(ctx.shard(tracks), own_k_ms, own_ms_per_step)
+    result["ranks_seen"] = len(result["ranks"])
     ex.close()
-    del count, frame, ms
+    del count, frame, ms, scratch_count
     return result
 
 
@@ -542,15 +699,22 @@ def cpu_baseline(ctx, state, n_streams):
     n_streams = min(n_streams, state["streams"])
     host = state["samples"][:n_streams, :n].cpu().numpy()
     cores, info = _host_cpus()
+    max_beats = state["max_beats"]
     t0 = time.perf_counter()
-    total, counts = bd_oracle.run_batch(okind, sr, host, L, n_threads=cores)
+    total, counts, cpu_idx, cpu_ms = bd_oracle.run_batch_lists(okind, sr, host, L, max_beats, n_threads=cores)
     dt = time.perf_counter() - t0
     one = max(1, n_streams // (cores * 2))
     t1 = time.perf_counter()
     bd_oracle.run_batch(okind, sr, host[:one], L, n_threads=1)
     dt1 = time.perf_counter() - t1
+    # stream by stream: the beat lists themselves (callback index and relative_ms of every beat), not their lengths
     gpu_counts = state["count"][:n_streams].cpu().numpy().astype(np.int64)
-    differing = np.nonzero(gpu_counts != counts.astype(np.int64))[0]
+    gpu_idx = state["idx"][:n_streams].cpu().numpy().astype(np.int64)
+    gpu_ms = state["ms"][:n_streams].cpu().numpy().astype(np.int64)
+    used = np.arange(max_beats)[None, :] < np.minimum(counts.astype(np.int64), max_beats)[:, None]
+    same = (gpu_counts == counts.astype(np.int64)) & \
+           ((gpu_idx == cpu_idx.astype(np.int64)) | ~used).all(axis=1) & ((gpu_ms == cpu_ms.astype(np.int64)) | ~used).all(axis=1)
+    differing = np.nonzero(~same)[0]
     out = {
         "value": n_streams * (n / sr) / dt,
         "unit": "audio-sec/s",
@@ -562,13 +726,14 @@ def cpu_baseline(ctx, state, n_streams):
         "cpu_events": int(total),
         "gpu_events_same_sample": int(gpu_counts.sum()),
         "streams_compared": int(n_streams),
+        "compared": "per stream, the whole beat list: callback index and relative_ms of every beat, bit-exact",
         "streams_differing": int(len(differing)),
         "streams_differing_list": [int(s) for s in differing[:64]],
         "value_1core": one * (n / sr) / dt1,
         "sample_1core": f"first {one} streams, 1 thread, {dt1:.1f} s",
     }
     out.update(info)
-    if kind_name == "Spectrum":
+    if kind_name == "Spectrum" and state.get("has_values"):
         out.update(_threshold_adjacent(ctx, state, host, n_streams, bd_oracle))
     return out
 
@@ -693,17 +858,27 @@ def main() -> None:
                     help="extra short measurements attached as `also` (auto: all at N = 1 with the default workload, "
                          "the chunked 131,072-track share at N > 1)")
     ap.add_argument("--also-tracks", type=int, default=0, help="tracks per GPU of the chunked `also` entry (rehearsals)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for the barrier / timing reduction (gloo: rehearsals)")
+    ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
+                    help="process-group backend for the barriers, the timing reduction and the per-rank report (the "
+                         "data path has no collective); the other one is the fallback if this one fails to initialise")
+    ap.add_argument("--group-timeout", type=float, default=600.0,
+                    help="seconds any wait on the process group may take before the rank gives up")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0,
+                    help="self-launched ranks (--gpus N without a launcher): wall limit in seconds, after which the "
+                         "ranks are ended and the launcher exits with 124")
+    ap.add_argument("--outputs", default="both", choices=["both", "values", "decisions"],
+                    help="the two strategies: time the launch that writes detection values, the one that writes "
+                         "decisions only, or both (default; profiling runs pick one)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (a box with one GPU)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="no GPU work: every rank joins a gloo group, the ranks' numbers are summed and rank 0 prints "
                          "them (checks the launcher on a machine without a GPU)")
+    ap.add_argument("--rehearse-sleep", type=float, default=0.0, help=argparse.SUPPRESS)   # tests: a rank that hangs
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args.gpus))        # nothing above touched the GPU
+        sys.exit(self_launch(args.gpus, args.launch_timeout))        # nothing above touched the GPU
 
     if args.rehearse_launch:
         return rehearse_launch(args)
@@ -716,9 +891,8 @@ def main() -> None:
         r.pop("workload")
         result, state = r, None
     else:
-        # (profiling runs pass --no-cpu-baseline: every launch of the dominant kernel is then of the timed kind)
         result, state = run_resident(ctx, args.workload, args.steps, args.warmup, args.streams, args.seconds,
-                                     with_values_too=not args.no_cpu_baseline)
+                                     outputs=args.outputs)
         if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(ctx, state, args.cpu_streams)
 
@@ -741,9 +915,13 @@ def main() -> None:
                 del st_
                 gc.collect()
                 torch.cuda.empty_cache()
-                also.append({"workload": w, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                             "steps": 3, "description": r["config"]["workload"], "events_found": r["config"]["beats_found"],
-                             "roofline": r["roofline"]})
+                e = {"workload": w, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                     "steps": 3, "description": r["config"]["workload"], "events_found": r["config"]["beats_found"],
+                     "outputs": r["config"]["outputs"], "roofline": r["roofline"]}
+                for k in ("value_decisions_only", "ms_per_step_decisions_only", "roofline_decisions_only"):
+                    if k in r:
+                        e[k] = r[k]
+                also.append(e)
         also.append(run_chunked_onset(ctx, 2, 1, tracks=args.also_tracks, chunk=args.chunk_tracks))
         if also_mode == "all" and ctx.rank == 0:
             also.append(run_live(ctx))

@@ -169,6 +169,7 @@ extern "C" {
     pub fn bd_live_create(kind: c_int, sampling_rate: u32, params: *const bd_params, n_streams: u32, max_callback_len: u32, depth: u32, device: c_int, out: *mut *mut bd_live) -> c_int;
     pub fn bd_live_set_on_beat(live: *mut bd_live, on_beat: bd_live_on_beat_fn, user: *mut c_void) -> c_int;
     pub fn bd_live_submit(live: *mut bd_live, samples: *const c_void, n: u32, format: c_int, tick_id: *mut u64) -> c_int;
+    pub fn bd_live_submit_ragged(live: *mut bd_live, samples: *const c_void, n_per_stream: *const u32, row_pitch: u32, format: c_int, tick_id: *mut u64) -> c_int;
     pub fn bd_live_poll(live: *mut bd_live, tick_id: u64, wait: c_int, beats: *mut u8, relative_ms: *mut u32, values: *mut f32) -> c_int;
     pub fn bd_live_destroy(live: *mut bd_live);
     pub fn bd_start_listening(on_beat: bd_on_beat_fn, on_beat_user: *mut c_void, source: *const bd_input_source, kind: c_int, keep_recording: *const c_int, out: *mut *mut bd_listener) -> c_int;
@@ -206,6 +207,7 @@ extern "C" {
 
     // instrumentation
     pub fn bd_last_kernel_name() -> *const c_char;
+    pub fn bd_tuning_reload();
     pub fn bd_probe_read(src: *const c_void, bytes: u64, sink: *mut u32, waves_per_cu: u32, hip_stream: *mut c_void) -> c_int;
     pub fn bd_probe_read_ex(src: *const c_void, bytes: u64, sink: *mut u32, waves_per_cu: u32, depth: u32, contiguous: u32, hip_stream: *mut c_void) -> c_int;
 }

@@ -235,6 +235,15 @@ int bd_live_set_on_beat(bd_live *live, bd_live_on_beat_fn on_beat, void *user);
 /* One tick: `samples` is host memory [n_streams][n] in `format`.  Returns once the
  * tick is staged and enqueued; *tick_id numbers ticks from 0. */
 int bd_live_submit(bd_live *live, const void *samples, uint32_t n, int format, uint64_t *tick_id);
+/* One tick in which every stream brings its own number of samples.  In the reference every stream is
+ * a device of its own whose closure receives its own data.len() (src/record.rs:93-95, :107-109,
+ * :121-123; "mostly 500-540" samples on Linux, src/strategies/spectrum.rs:40-42), so concurrent streams
+ * do not deliver equal lengths on one tick.  `samples` is host memory [n_streams][row_pitch] in `format`
+ * (row_pitch <= max_callback_len; the whole block is copied); stream m's callback is the first
+ * n_per_stream[m] <= row_pitch samples of its row.  A stream with n_per_stream[m] == 0 skips the tick:
+ * no is_beat call happens for it, its ring and clock do not advance, its result is "no beat". */
+int bd_live_submit_ragged(bd_live *live, const void *samples, const uint32_t *n_per_stream, uint32_t row_pitch,
+                          int format, uint64_t *tick_id);
 /* Result of a tick: 1 = done (outputs filled, each [n_streams] or NULL), 0 = not
  * finished yet (wait == 0), < 0 error.  Without an on_beat callback every tick must
  * be polled before its slot is reused. */
@@ -424,6 +433,12 @@ void bd_chunked_destroy(bd_chunked *ex);
 /* Name and grid of the dominant kernel of the last bd_analyze_batch call on
  * this thread (for profilers). */
 const char *bd_last_kernel_name(void);
+/* The library's experiment switches (environment variables BD_SPEC_*, BD_SPLIT_*, BD_LPF_VARIANT,
+ * BD_HOST_*: kernel routing and staging variants used by tests and tuning scripts; every default is the
+ * measured best) are read from the environment once, on first use, never on a launch path.  This call
+ * reads them again; launches that run on other threads at that moment use either snapshot.
+ * No counterpart in the reference. */
+void bd_tuning_reload(void);
 /* Read-bandwidth probe: streams `bytes` of device memory through the same kind of
  * loads the analysis kernels use and does nothing else; timing it gives the
  * ceiling those kernels are compared with.  `sink` (device, 256 * waves_per_cu

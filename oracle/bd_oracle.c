@@ -486,6 +486,7 @@ size_t bdo_run_stream(int kind, uint32_t sampling_rate, const bdo_params *p,
 typedef struct batch_job {
     int kind; uint32_t sr; const bdo_params *p; const int16_t *samples;
     size_t s0, s1, n_samples, stride, cb; uint32_t *beat_count; uint64_t total;
+    uint32_t *beat_idx, *beat_ms; size_t max_beats;   /* optional: the lists themselves, [n_streams][max_beats] */
 } batch_job;
 
 static void *batch_worker(void *arg)
@@ -494,7 +495,9 @@ static void *batch_worker(void *arg)
     j->total = 0;
     for (size_t s = j->s0; s < j->s1; s++) {
         size_t b = bdo_run_stream(j->kind, j->sr, j->p, j->samples + s * j->stride,
-                                  j->n_samples, j->cb, 0, NULL, NULL, NULL, NULL, 0);
+                                  j->n_samples, j->cb, 0, NULL, NULL,
+                                  j->beat_idx ? j->beat_idx + s * j->max_beats : NULL,
+                                  j->beat_ms ? j->beat_ms + s * j->max_beats : NULL, j->max_beats);
         if (j->beat_count) j->beat_count[s] = (uint32_t)b;
         j->total += b;
     }
@@ -506,6 +509,15 @@ uint64_t bdo_run_batch(int kind, uint32_t sampling_rate, const bdo_params *p,
                        size_t stream_stride, size_t callback_len, int n_threads,
                        uint32_t *beat_count)
 {
+    return bdo_run_batch_lists(kind, sampling_rate, p, samples, n_streams, n_samples, stream_stride,
+                               callback_len, n_threads, beat_count, NULL, NULL, 0);
+}
+
+uint64_t bdo_run_batch_lists(int kind, uint32_t sampling_rate, const bdo_params *p,
+                             const int16_t *samples, size_t n_streams, size_t n_samples,
+                             size_t stream_stride, size_t callback_len, int n_threads,
+                             uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, size_t max_beats)
+{
     if (n_threads < 1) n_threads = 1;
     if ((size_t)n_threads > n_streams) n_threads = (int)(n_streams ? n_streams : 1);
     pthread_once(&g_fft_once, fft_init);
@@ -516,6 +528,7 @@ uint64_t bdo_run_batch(int kind, uint32_t sampling_rate, const bdo_params *p,
         jobs[t].samples = samples; jobs[t].n_samples = n_samples;
         jobs[t].stride = stream_stride; jobs[t].cb = callback_len;
         jobs[t].beat_count = beat_count;
+        jobs[t].beat_idx = beat_idx; jobs[t].beat_ms = beat_ms; jobs[t].max_beats = max_beats;
         jobs[t].s0 = n_streams * (size_t)t / (size_t)n_threads;
         jobs[t].s1 = n_streams * (size_t)(t + 1) / (size_t)n_threads;
         if (n_threads == 1) batch_worker(&jobs[t]);

@@ -138,6 +138,13 @@ uint64_t bdo_run_batch(int kind, uint32_t sampling_rate, const bdo_params *p,
                        const int16_t *samples, size_t n_streams, size_t n_samples,
                        size_t stream_stride, size_t callback_len, int n_threads,
                        uint32_t *beat_count /*[n_streams] or NULL*/);
+/* The same, and the beat lists themselves: callback index and relative_ms of the first max_beats
+ * beats of every stream ([n_streams][max_beats], either may be NULL), as the harness loop of
+ * lib.rs:286-292 would print them. */
+uint64_t bdo_run_batch_lists(int kind, uint32_t sampling_rate, const bdo_params *p,
+                             const int16_t *samples, size_t n_streams, size_t n_samples,
+                             size_t stream_stride, size_t callback_len, int n_threads,
+                             uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms, size_t max_beats);
 
 /* float64 direct DFT of the retained bins, for error analysis of the f32 FFT
  * (no reference counterpart). */

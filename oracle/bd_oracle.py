@@ -99,6 +99,8 @@ def lib() -> C.CDLL:
     L.bdo_run_stream.restype = sz
     L.bdo_run_batch.argtypes = [C.c_int, u32, C.POINTER(Params), vp, sz, sz, sz, sz, C.c_int, vp]
     L.bdo_run_batch.restype = u64
+    L.bdo_run_batch_lists.argtypes = [C.c_int, u32, C.POINTER(Params), vp, sz, sz, sz, sz, C.c_int, vp, vp, vp, sz]
+    L.bdo_run_batch_lists.restype = u64
     _lib = L
     return L
 
@@ -208,6 +210,20 @@ def run_batch(kind: int, sampling_rate: int, samples2d, callback_len: int, param
     total = lib().bdo_run_batch(kind, sampling_rate, C.byref(p), _vp(a), n_streams, n, n, callback_len, n_threads,
                                 _vp(counts))
     return int(total), counts
+
+
+def run_batch_lists(kind: int, sampling_rate: int, samples2d, callback_len: int, max_beats: int,
+                    params: Params | None = None, n_threads: int = 1):
+    """(total, counts[n_streams], beat_idx[n_streams][max_beats], beat_ms[...]); unused entries are 0."""
+    a = np.ascontiguousarray(samples2d, dtype=np.int16)
+    n_streams, n = a.shape
+    counts = np.zeros(n_streams, dtype=np.uint32)
+    idx = np.zeros((n_streams, max_beats), dtype=np.uint32)
+    ms = np.zeros((n_streams, max_beats), dtype=np.uint32)
+    p = params if params is not None else default_params()
+    total = lib().bdo_run_batch_lists(kind, sampling_rate, C.byref(p), _vp(a), n_streams, n, n, callback_len, n_threads,
+                                      _vp(counts), _vp(idx), _vp(ms), max_beats)
+    return int(total), counts, idx, ms
 
 
 def u16_data_to_i16(data) -> np.ndarray:

@@ -45,6 +45,27 @@ def bd():
     return beat_detector_amd
 
 
+@pytest.fixture
+def knobs(monkeypatch, bd):
+    """Experiment switches of the library (BD_* environment variables).  The library reads its
+    environment once, so every change is published with bd_tuning_reload, the restored environment
+    at the end of the test included."""
+    L = bd.lib()
+
+    class Knobs:
+        def set(self, name, value):
+            monkeypatch.setenv(name, str(value))
+            L.bd_tuning_reload()
+
+        def unset(self, name):
+            monkeypatch.delenv(name, raising=False)
+            L.bd_tuning_reload()
+
+    yield Knobs()
+    monkeypatch.undo()
+    L.bd_tuning_reload()
+
+
 @pytest.fixture(scope="session")
 def oracle_ext():
     from oracle import bd_oracle_ext

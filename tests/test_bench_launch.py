@@ -28,8 +28,20 @@ def test_self_launch_starts_one_process_per_gpu():
                          env=_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     r = _last_json(out.stdout)
-    assert r["ranks"] == 2 and r["rank_sum"] == 1 and r["local_rank_sum"] == 1
+    _check_rank_reports(r, 2)
+    assert r["backend"] == "gloo"                            # the default: no RCCL needed for barriers
     assert r["shards"] == [[0, 16384], [16384, 32768]]       # contiguous, equal shards (weak scaling)
+
+
+def _check_rank_reports(r, n):
+    """The keys a multi-GPU run's JSON carries so that a reader can see N distinct ranks took part."""
+    assert r["ranks_seen"] == n and len(r["ranks"]) == n
+    assert [x["rank"] for x in r["ranks"]] == list(range(n))
+    assert [x["local_rank"] for x in r["ranks"]] == list(range(n))
+    assert len({x["pid"] for x in r["ranks"]}) == n          # one process per rank
+    for x in r["ranks"]:
+        for key in ("host", "device_index", "device_name", "device_id", "shard", "kernel_ms"):
+            assert key in x
 
 
 def test_under_torch_distributed_run_it_is_a_rank():
@@ -41,7 +53,29 @@ def test_under_torch_distributed_run_it_is_a_rank():
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--rehearse-launch"], env=_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    assert _last_json(out.stdout)["ranks"] == 2
+    _check_rank_reports(_last_json(out.stdout), 2)
+
+
+def test_backend_falls_back_when_the_first_choice_fails():
+    # without a GPU, nccl cannot initialise: the group comes up over gloo and says so
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                          "--backend", "nccl"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    r = _last_json(out.stdout)
+    assert r["backend"] == "gloo" and r["ranks_seen"] == 2
+    assert r["backend_notes"] and r["backend_notes"][0].startswith("nccl:")     # why the first choice was dropped
+
+
+def test_launch_wall_limit_ends_the_ranks():
+    # ranks that never finish (they sleep): the launcher ends them at its wall limit and exits non-zero
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-launch",
+                          "--rehearse-sleep", "120", "--launch-timeout", "8"],
+                         env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 124, (out.returncode, out.stderr)
+    assert time.monotonic() - t0 < 60
+    assert "--launch-timeout" in out.stderr
 
 
 def test_a_failing_rank_ends_the_launch():

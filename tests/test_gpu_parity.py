@@ -179,12 +179,12 @@ def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
 
 
 @pytest.mark.parametrize("L", [63, 126, 441, 504, 693, 819])
-def test_spectrum_granules_of_63_samples(bd, oracle, monkeypatch, L):
+def test_spectrum_granules_of_63_samples(bd, oracle, knobs, L):
     """Callback lengths 63 q up to 819 (441 = 10 ms at 44.1 kHz): granules of 63 samples; short streams,
     partial steps, several runs, rows that are only 2-byte aligned, the unpinned choices.  (With three
     bins or fewer the split kernel takes 129 .. 767 samples by default: switched off here.)"""
     import torch
-    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")
+    knobs.set("BD_SPEC_NO_SPLIT", "1")
     for n, streams in ((40000, 3), (4032 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4032 * 40 + 5, 1), (1024 + L, 2)):
         x = _synth(bd, streams, n, first=3)
         _compare(bd, oracle, "Spectrum", SR, x, L)
@@ -206,9 +206,9 @@ def test_spectrum_granules_of_63_samples(bd, oracle, monkeypatch, L):
 
 
 @pytest.mark.parametrize("L", [7, 441, 1000, 1500])
-def test_spectrum_generic_kernel_alone(bd, oracle, monkeypatch, L):
+def test_spectrum_generic_kernel_alone(bd, oracle, knobs, L):
     """The generic kernel on every callback (what sampling rates with more than three kept bins use)."""
-    monkeypatch.setenv("BD_SPEC_NO_GRANULE", "1")
+    knobs.set("BD_SPEC_NO_GRANULE", "1")
     x = _synth(bd, 2, 40000, first=3)
     _compare(bd, oracle, "Spectrum", SR, x, L)
     assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
@@ -219,12 +219,12 @@ def test_spectrum_generic_kernel_alone(bd, oracle, monkeypatch, L):
 
 @pytest.mark.parametrize("L", [64, 128, 192, 256, 448, 960, 1536, 2048, 3008, 4096,
                                32, 96, 160, 480, 16, 48, 240])
-def test_spectrum_granule_callback_lengths(bd, oracle, monkeypatch, L):
+def test_spectrum_granule_callback_lengths(bd, oracle, knobs, L):
     """Multiples of 64 other than 512 / 1024, of 32 up to 512 and of 16 up to 256: the granule kernel
     (granules of 64, 32, 16 samples); short streams, partial steps,
     a stream long enough to be split into runs, and the generic kernel on the same data.  (With three
     bins or fewer the split kernel takes 129 .. 767 samples off the 64-sample grid by default: switched off here.)"""
-    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")
+    knobs.set("BD_SPEC_NO_SPLIT", "1")
     for n, streams in ((40000, 3), (4096 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4096 * 40 + 5, 1)):
         x = _synth(bd, streams, n, first=3)
         res, ref_v, _, _ = _compare(bd, oracle, "Spectrum", SR, x, L)
@@ -236,17 +236,17 @@ def test_spectrum_granule_callback_lengths(bd, oracle, monkeypatch, L):
         _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
 
 
-def test_spectrum_granule_equals_generic(bd, oracle, monkeypatch):
+def test_spectrum_granule_equals_generic(bd, oracle, knobs):
     import torch
-    monkeypatch.setenv("BD_SPEC_NO_SPLIT", "1")     # 480 and 240 would take the split kernel
+    knobs.set("BD_SPEC_NO_SPLIT", "1")     # 480 and 240 would take the split kernel
     x = torch.from_numpy(np.ascontiguousarray(np.pad(_synth(bd, 4, 4096 * 9 + 100, first=1), ((0, 0), (0, 28))))).cuda()
     n = 4096 * 9 + 100
     for L in (256, 2048, 704, 480, 240):
         v1, f1 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
-        monkeypatch.setenv("BD_SPEC_NO_GRANULE", "1")
+        knobs.set("BD_SPEC_NO_GRANULE", "1")
         v2, f2 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, x, L, n_samples=n)
         assert bd.last_kernel_name() == "bd_spectrum_generic_kernel"
-        monkeypatch.delenv("BD_SPEC_NO_GRANULE")
+        knobs.unset("BD_SPEC_NO_GRANULE")
         assert torch.equal(f1, f2)
         assert torch.isclose(v1, v2, rtol=1e-5, atol=1.0).all()
 
@@ -558,12 +558,12 @@ def test_host_pointer_entry_points(bd, oracle):
                 assert res.beats(s) == ref_b[s]
 
 
-def test_host_entry_in_many_chunks(bd, oracle, monkeypatch):
+def test_host_entry_in_many_chunks(bd, oracle, knobs):
     """The host-pointer entry with chunks of 3 streams (two slots reused many times), all outputs requested."""
     n = SR * 2 + 100
     x = np.zeros((20, n + 37), dtype=np.int16)
     x[:, :n] = _synth(bd, 20, n, first=200)
-    monkeypatch.setenv("BD_HOST_CHUNK_BYTES", str(3 * ((n + 63) & ~63) * 2))
+    knobs.set("BD_HOST_CHUNK_BYTES", str(3 * ((n + 63) & ~63) * 2))
     for kind, okind in ((bd.StrategyKind.Spectrum, oracle.KIND_SPECTRUM), (bd.StrategyKind.LPF, oracle.KIND_LPF)):
         _, ref_c, ref_b = util.oracle_batch(oracle, okind, SR, x[:, :n], 512)
         res = bd.analyze_batch_host(kind, SR, x[:, :n], 512)
@@ -659,16 +659,16 @@ def test_ragged_batch(bd, oracle, kind_name):
             np.testing.assert_array_equal(res.flags[i, :len(c)].cpu().numpy(), c)
 
 
-def test_tuning_knobs_do_not_change_results(bd, oracle, monkeypatch):
+def test_tuning_knobs_do_not_change_results(bd, oracle, knobs):
     """Every value of the experiment knobs selects code that must give the same answers."""
     x = _synth(bd, 4, SR * 10, first=60)
     for run in ("8", "16", "64", "256", "512"):
-        monkeypatch.setenv("BD_SPEC_RUN", run)
+        knobs.set("BD_SPEC_RUN", run)
         for L in (512, 1024):
             _compare(bd, oracle, "Spectrum", SR, x, L)
-    monkeypatch.delenv("BD_SPEC_RUN")
+    knobs.unset("BD_SPEC_RUN")
     for variant in ("1", "2", "3"):
-        monkeypatch.setenv("BD_LPF_VARIANT", variant)
+        knobs.set("BD_LPF_VARIANT", variant)
         for L in (1024, 64, 4096, 136):
             _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 

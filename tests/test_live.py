@@ -230,3 +230,87 @@ def test_live_formats_and_lengths_mixed_in_one_engine(bd, oracle):
             assert (int(ms[m]) if beats[m] else None) == want, (t, m, fmt, n)
         pos += n
     live.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind_name", ["Spectrum", "LPF"])
+def test_live_ragged_ticks_256_streams_each_with_its_own_lengths(bd, oracle, kind_name):
+    """In the reference every stream is a device of its own whose closure gets its own data.len()
+    (record.rs:93-95, 107-109, 121-123): 256 streams, each drawing its own 500-540 samples per tick (and
+    now and then nothing at all) for 1,000 ticks through bd_live_submit_ragged; every stream must equal
+    its own reference detector call by call, and a stream that skips a tick must not advance."""
+    M, ticks, pitch = 256, 1000, 540
+    rng = np.random.default_rng(21)
+    lengths = rng.integers(500, 541, (ticks, M)).astype(np.uint32)
+    lengths[rng.random((ticks, M)) < 0.02] = 0                  # this stream's device delivered nothing
+    lengths[0, :8] = 0                                          # also on the very first tick
+    total = lengths.sum(axis=0)
+    x = bd.synth_fill_host(M, int(total.max()), first_stream=500, seed=80)
+    kind = bd.StrategyKind[kind_name]
+    okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+    live = bd.Live(kind, SR, M, max_callback_len=pitch, depth=4)
+    pos = np.zeros(M, dtype=np.int64)
+    col = np.arange(pitch)[None, :]
+    results = []
+    for t in range(ticks):
+        src = np.minimum(pos[:, None] + col, x.shape[1] - 1)
+        block = np.take_along_axis(x, src, axis=1)              # row m: the stream's next samples, whatever follows them
+        beats, ms, vals = live.poll(live.submit_ragged(block, lengths[t]))
+        results.append((beats.copy(), ms.copy(), vals.copy()))
+        pos += lengths[t]
+    live.close()
+    refs = [oracle.OracleDetector(okind, SR) for _ in range(M)]
+    pos[:] = 0
+    n_beats = 0
+    for t in range(ticks):
+        beats, ms, vals = results[t]
+        for m in range(M):
+            n = int(lengths[t, m])
+            if n == 0:
+                assert beats[m] == 0 and ms[m] == 0 and vals[m] == 0.0, (t, m)
+                continue
+            want = refs[m].is_beat(x[m, pos[m]:pos[m] + n])
+            assert (int(ms[m]) if beats[m] else None) == want, (t, m)
+            n_beats += want is not None
+        pos += lengths[t]
+    assert n_beats > 1000
+
+
+@pytest.mark.gpu
+def test_live_ragged_ticks_in_every_format_and_argument_errors(bd, oracle):
+    M, ticks, pitch = 16, 120, 700
+    rng = np.random.default_rng(22)
+    lengths = rng.integers(0, pitch + 1, (ticks, M)).astype(np.uint32)
+    live = bd.Live(bd.StrategyKind.Spectrum, SR, M, max_callback_len=pitch, depth=2)
+    refs = [oracle.OracleDetector(oracle.KIND_SPECTRUM, SR) for _ in range(M)]
+    x = bd.synth_fill_host(M, ticks * pitch, first_stream=9, seed=81)
+    for t in range(ticks):
+        blk = np.ascontiguousarray(x[:, t * pitch:(t + 1) * pitch])
+        fmt = (bd.FMT_I16, bd.FMT_U16, bd.FMT_F32)[t % 3]
+        if fmt == bd.FMT_U16:
+            raw = rng.integers(0, 65536, blk.shape).astype(np.uint16)
+            want_in = oracle.u16_data_to_i16(raw)
+        elif fmt == bd.FMT_F32:
+            raw = (blk.astype(np.float32) / 32767.0).astype(np.float32)
+            want_in = oracle.f32_data_to_i16(raw)
+        else:
+            raw, want_in = blk, blk
+        beats, ms, _ = live.poll(live.submit_ragged(raw, lengths[t], fmt))
+        for m in range(M):
+            n = int(lengths[t, m])
+            if n == 0:
+                assert beats[m] == 0
+                continue
+            want = refs[m].is_beat(want_in[m, :n])
+            assert (int(ms[m]) if beats[m] else None) == want, (t, m, fmt, n)
+    # equal ticks and ragged ticks mix in one engine
+    blk = np.ascontiguousarray(x[:, :512])
+    beats, ms, _ = live.poll(live.submit(blk))
+    for m in range(M):
+        want = refs[m].is_beat(blk[m])
+        assert (int(ms[m]) if beats[m] else None) == want
+    with pytest.raises(bd.BeatDetectorError):
+        live.submit_ragged(np.zeros((M, pitch + 1), dtype=np.int16), np.zeros(M, dtype=np.uint32))   # pitch > max
+    with pytest.raises(bd.BeatDetectorError):
+        live.submit_ragged(np.zeros((M, 10), dtype=np.int16), np.full(M, 11, dtype=np.uint32))       # length > pitch
+    live.close()

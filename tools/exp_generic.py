@@ -21,7 +21,7 @@ for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
 for o in out:
     print(o)
 if os.environ.get("BD_AB_SMALL"):
-    os.environ["BD_SPEC_NO_SMALL_GRANULE"] = "1"
+    os.environ["BD_SPEC_NO_SMALL_GRANULE"] = "1"; bd.lib().bd_tuning_reload()
     for L in (480, 160, 240, 720, 96, 48):
         for _ in range(2):
             bd.batch_candidates(bd.StrategyKind.Spectrum, sr, buf, L, n_samples=n)

@@ -9,7 +9,7 @@ for streams, seconds in ((4096, 60),):
     n = sr * seconds
     x = bd.synth_fill_host(streams, n, seed=3)
     for thr in (2, 4, 8, 16, 32):
-      os.environ['BD_HOST_THREADS'] = str(thr)
+      os.environ['BD_HOST_THREADS'] = str(thr); bd.lib().bd_tuning_reload()
       for kind in (bd.StrategyKind.Spectrum,):
         ts = []
         for rep in range(3):

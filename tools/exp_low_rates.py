@@ -10,7 +10,7 @@ for sr in (44100, 24000, 22050, 16000, 11025, 8000):
     bd.synth_fill(buf, n_samples=n, seed=1, sampling_rate=sr)
     row = []
     for env in ({}, {"BD_SPEC_NO_GRANULE": "1"}):
-        os.environ.pop("BD_SPEC_NO_GRANULE", None); os.environ.update(env)
+        os.environ.pop("BD_SPEC_NO_GRANULE", None); os.environ.update(env); bd.lib().bd_tuning_reload()
         for L in (512, 1024, 160, 441):
             for _ in range(2):
                 bd.batch_candidates(bd.StrategyKind.Spectrum, sr, buf, L, n_samples=n)

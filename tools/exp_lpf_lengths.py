@@ -9,7 +9,7 @@ bd.synth_fill(buf, n_samples=n, seed=1)
 for env in ({}, {"BD_LPF_VARIANT": "4"}, {"BD_LPF_LINES": "1"}, {"BD_LPF_LINES": "1", "BD_LPF_VARIANT": "4"}):
     for k in ("BD_LPF_VARIANT", "BD_LPF_LINES"):
         os.environ.pop(k, None)
-    os.environ.update(env)
+    os.environ.update(env); bd.lib().bd_tuning_reload()
     row = []
     for L in (441, 882, 1000, 1500, 480, 160, 100, 1024):
         for _ in range(2):

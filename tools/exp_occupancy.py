@@ -20,8 +20,8 @@ def t():
     return round(a.elapsed_time(b) / 4, 2)
 out = []
 for pad in (0, 10000, 22000, 30000, 43000, 70000, 0):
-    os.environ["BD_SPEC_LDS_PAD"] = str(pad)
+    os.environ["BD_SPEC_LDS_PAD"] = str(pad); bd.lib().bd_tuning_reload()
     for run in (128, 512):
-        os.environ["BD_SPEC_RUN"] = str(run)
+        os.environ["BD_SPEC_RUN"] = str(run); bd.lib().bd_tuning_reload()
         out.append((pad, run, t()))
 print("lds_pad, run, ms:", out, flush=True)

@@ -18,6 +18,6 @@ def t(v):
     return round(a.elapsed_time(b) / 3, 2)
 out = []
 for run in (128, 64, 256, 512, 128):
-    os.environ["BD_SPEC_RUN"] = str(run)
+    os.environ["BD_SPEC_RUN"] = str(run); bd.lib().bd_tuning_reload()
     out.append((run, t(vals), t(None)))
 print("run, with values, flags only:", out, flush=True)
