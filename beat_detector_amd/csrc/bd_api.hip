@@ -91,11 +91,12 @@ static const bd_tuning *bd_tuning_read()
     bd_tuning *t = new bd_tuning();
     t->spec_force_granule = set("BD_SPEC_FORCE_GRANULE");
     t->spec_run = (int)num("BD_SPEC_RUN");
-    const long long pad = num("BD_SPEC_LDS_PAD");
-    t->spec_lds_pad = pad < 0 ? 0u : (pad > 150000 ? 150000u : (unsigned)pad);
+    const long long pad = getenv("BD_SPEC_LDS_PAD") ? num("BD_SPEC_LDS_PAD") : -1;
+    t->spec_lds_pad = pad < 0 ? -1 : (pad > 140000 ? 140000 : (int)pad);
     t->spec_no_split = set("BD_SPEC_NO_SPLIT");
     t->spec_no_granule = set("BD_SPEC_NO_GRANULE");
     t->spec_no_small_granule = set("BD_SPEC_NO_SMALL_GRANULE");
+    t->spec_depth = (int)num("BD_SPEC_DEPTH");
     t->spec_store = (int)num("BD_SPEC_STORE");
     t->split_no_rem = set("BD_SPLIT_NO_REM");
     t->split_no_stage = set("BD_SPLIT_NO_STAGE");

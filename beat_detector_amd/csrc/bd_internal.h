@@ -43,10 +43,11 @@ int  bd_check_hip(hipError_t e, const char *what);
 struct bd_tuning {
     int      spec_force_granule;     // BD_SPEC_FORCE_GRANULE: 512 / 1024 through the granule kernel
     int      spec_run;               // BD_SPEC_RUN: half-blocks per task of the half-block kernel (0 = automatic)
-    unsigned spec_lds_pad;           // BD_SPEC_LDS_PAD: unused dynamic LDS, caps the half-block kernel's residency
+    int      spec_lds_pad;           // BD_SPEC_LDS_PAD: unused dynamic LDS, caps the half-block kernel's residency (-1 = default)
     int      spec_no_split;          // BD_SPEC_NO_SPLIT: no split kernel
     int      spec_no_granule;        // BD_SPEC_NO_GRANULE: generic kernel for everything off the half-block path
     int      spec_no_small_granule;  // BD_SPEC_NO_SMALL_GRANULE: no granules below 64 samples
+    int      spec_depth;             // BD_SPEC_DEPTH: register buffers of the half-block kernel (2, 3, 4; 0 = default)
     int      spec_store;             // BD_SPEC_STORE: result-store variant of the half-block kernel (0 = default)
     int      split_no_rem;           // BD_SPLIT_NO_REM: remainder as a masked piece of the main loop
     int      split_no_stage;         // BD_SPLIT_NO_STAGE: no LDS staging for lengths that are not multiples of 4

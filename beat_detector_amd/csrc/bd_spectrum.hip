@@ -61,12 +61,19 @@ static __device__ const float bd_sin1024[1024] = {
 #include "bd_sin1024.inc"
 };
 
-// loads the four 16-byte pieces of one lane: half-block `hb`, bytes 256 c + 16 l
-__device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], const int16_t *sp, int64_t hb, int l)
+// The four 16-byte pieces of one lane (bytes 256 c + 16 l of its half-block) at byte offset `off`
+// of the run, through a buffer descriptor that spans exactly the half-blocks the run may read: a
+// piece outside it -- the rows before the first half-block of a hop-512 run, the rows and the
+// look-ahead iterations past its last one -- is dropped by the range check (it returns zeros and
+// touches no memory), so every load of the loop is unconditional and the compiler can count them
+// (s_waitcnt vmcnt(N) instead of vmcnt(0)) whatever the depth of the pipeline.
+__device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], __amdgpu_buffer_rsrc_t rs, unsigned off)
 {
-    const uint4 *p = reinterpret_cast<const uint4 *>(sp + hb * BD_HALF_BLOCK) + l;
 #pragma unroll
-    for (int c = 0; c < 4; c++) d[c] = bd_load_stream16(p + 16 * c);
+    for (int c = 0; c < 4; c++) {
+        const bd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 256u * c, 0, 2 /* nt */);
+        d[c] = make_uint4(v.x, v.y, v.z, v.w);
+    }
 }
 
 #ifndef BD_SPEC_MAX_RUN
@@ -189,7 +196,8 @@ __device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_s
 
 // MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
 // NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
-template <int MODE, int NK, bool NYQ>
+// DEPTH: register buffers of one iteration (4 KB per wavefront) each; loads run DEPTH - 1 iterations ahead.
+template <int MODE, int NK, bool NYQ, int DEPTH>
 __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
 {
     const int lane = threadIdx.x & 63;
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const int n_it = (int)((left < (int64_t)a.run_hbs ? left + 3 : (int64_t)a.run_hbs) / 4);
     // hop 512: the first callback of a run needs the half-block before the run
     const int it_begin = (MODE == 0 && hb0 > 0) ? -1 : 0;
-    const int64_t hb_lo = (MODE == 0) ? hb0 - 1 : hb0;
+    const int64_t hb_lo = (MODE == 0 && hb0 > 0) ? hb0 - 1 : hb0;   // first half-block the run reads
 
     const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
     const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
@@ -227,37 +235,37 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         slots->misc[0] = zm;
     }
 
-    // Two register buffers, each filled one iteration ahead of its use.  Loads
-    // are unconditional so that the compiler can count them (s_waitcnt vmcnt(4)
-    // instead of vmcnt(0)): a half-block outside [hb_lo, n_hb) is replaced by
-    // the nearest one inside (a line some lane of this wavefront reads anyway).
-    // Rows that loaded such a stand-in produce sums that no stored result uses.
-    uint4 A[4], B[4];
-    auto load = [&](uint4 (&d)[4], int it) {
-        int64_t hb = hb0 + 4 * (int64_t)it + g;
-        hb = hb < hb_lo ? hb_lo : hb;
-        hb = hb < n_hb - 1 ? hb : n_hb - 1;
-        bd_load_hb(d, sp, hb, l);
-    };
+    // DEPTH register buffers in a ring, each filled DEPTH - 1 iterations ahead of its use.  Rows whose
+    // loads were dropped produce sums of zeros that no stored result uses.
+    const int64_t hb_end = n_hb < hb0 + (int64_t)a.run_hbs ? n_hb : hb0 + (int64_t)a.run_hbs;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<int16_t *>(sp + hb_lo * BD_HALF_BLOCK), 0, (int)((hb_end - hb_lo) * BD_HALF_BLOCK * 2), 0x00020000);
+    // byte offset of this lane's first piece in iteration 0, counted from half-block hb_lo (negative,
+    // i.e. out of range as an unsigned offset, for the rows of iteration -1 before it)
+    const int lane_off = (int)(hb0 - hb_lo + g) * (BD_HALF_BLOCK * 2) + 16 * l;
+    uint4 R[DEPTH][4];
+    auto load = [&](uint4 (&d)[4], int it) { bd_load_hb(d, rs, (unsigned)(lane_off + it * (4 * BD_HALF_BLOCK * 2))); };
     auto run = [&](const uint4 (&d)[4], int it) {
         bd_spec_iter<MODE, NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
     };
-    // Steady state: every load is issued one iteration ahead of its use.  The
-    // last one or two iterations are peeled so that nothing is loaded twice.
-    int it = it_begin;
-    load(A, it);
-    for (; it + 2 < n_it; it += 2) {
-        load(B, it + 1);
-        run(A, it);
-        load(A, it + 2);
-        run(B, it + 1);
-    }
-    if (it + 1 < n_it) {
-        load(B, it + 1);
-        run(A, it);
-        run(B, it + 1);
-    } else {
-        run(A, it);
+    {
+        int it = it_begin;
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; d++) load(R[d], it + d);
+        // whole trips of DEPTH iterations (one entry, one back edge, no exit inside: the waits between
+        // a load and its use stay counted), then the up to DEPTH - 1 iterations left, without loads
+        const int total = n_it - it_begin;
+        for (int trip = total / DEPTH; trip > 0; trip--) {
+#pragma unroll
+            for (int b = 0; b < DEPTH; b++) {
+                load(R[(b + DEPTH - 1) % DEPTH], it + DEPTH - 1);
+                run(R[b], it);
+                ++it;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < DEPTH - 1; b++)
+            if (it < n_it) { run(R[b], it); ++it; }
     }
     // results of the run: consecutive lanes finish and store consecutive callbacks
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -611,11 +619,18 @@ static void bd_win_launch(bool nyq, bool whole, const bd_win_args &a, dim3 grid,
 }
 
 // ---- launcher ---------------------------------------------------------------
-template <int MODE, int NK>
-static void launch_fast(bool nyq, const bd_spec_args &a, dim3 grid, unsigned lds_pad, hipStream_t st)
+template <int MODE, int NK, int DEPTH>
+static void launch_fast2(bool nyq, const bd_spec_args &a, dim3 grid, unsigned lds_pad, hipStream_t st)
 {
-    if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true>), dim3(grid), dim3(256), lds_pad, st, a);
-    else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false>), dim3(grid), dim3(256), lds_pad, st, a);
+    if (nyq) hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, true, DEPTH>), dim3(grid), dim3(256), lds_pad, st, a);
+    else     hipLaunchKernelGGL((bd_spectrum_band_kernel<MODE, NK, false, DEPTH>), dim3(grid), dim3(256), lds_pad, st, a);
+}
+template <int MODE, int NK>
+static void launch_fast(bool nyq, int depth, const bd_spec_args &a, dim3 grid, unsigned lds_pad, hipStream_t st)
+{
+    if (depth == 2) launch_fast2<MODE, NK, 2>(nyq, a, grid, lds_pad, st);
+    else if (depth == 4) launch_fast2<MODE, NK, 4>(nyq, a, grid, lds_pad, st);
+    else launch_fast2<MODE, NK, 3>(nyq, a, grid, lds_pad, st);
 }
 
 int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
@@ -638,7 +653,9 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         a.n_hb = (uint32_t)n_hb;
         // run length: long runs amortise the one re-read half-block at each run
         // start; short streams still need enough wavefronts to fill 256 CUs.
-        uint32_t run = 128;
+        // (Measured on 16,384 streams x 60 s with two workgroups per CU: runs of 64 half-blocks 12.4 ms,
+        // of 128 12.65 ms, of 32 12.9 ms.)
+        uint32_t run = 64;
         while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
         const int run_override = tune.spec_run;
         if (run_override >= 8 && run_override % 8 == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
@@ -652,18 +669,23 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         dim3 grid_dims;
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
         const dim3 grid = grid_dims;
-        // unused dynamic LDS caps the workgroups resident per CU (experiment switch)
-        const unsigned lds_pad = tune.spec_lds_pad;
+        // Unused dynamic LDS caps the workgroups resident per CU at two (eight wavefronts): the read
+        // stream then comes from a quarter as many places at once, and the launch is faster than with
+        // the 32 wavefronts per CU that registers and LDS would allow (16,384 streams x 60 s: 12.4 ms
+        // against 12.7 - 12.9 ms, and the result stores cost less on top).  Eight wavefronts with two
+        // iterations (8 KB) in flight each cover the memory latency; four do not (13.5 ms and more).
+        const unsigned lds_pad = tune.spec_lds_pad >= 0 ? (unsigned)tune.spec_lds_pad : 64000u;
+        const int depth = tune.spec_depth ? tune.spec_depth : 2;
         const int nk = plan.last_bin; // bins 1..last_bin
         const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
         if (callback_len == 512) {
-            if (nk == 0) launch_fast<0, 0>(nyq, a, grid, lds_pad, st);
-            else if (nk == 1) launch_fast<0, 1>(nyq, a, grid, lds_pad, st);
-            else launch_fast<0, 2>(nyq, a, grid, lds_pad, st);
+            if (nk == 0) launch_fast<0, 0>(nyq, depth, a, grid, lds_pad, st);
+            else if (nk == 1) launch_fast<0, 1>(nyq, depth, a, grid, lds_pad, st);
+            else launch_fast<0, 2>(nyq, depth, a, grid, lds_pad, st);
         } else {
-            if (nk == 0) launch_fast<1, 0>(nyq, a, grid, lds_pad, st);
-            else if (nk == 1) launch_fast<1, 1>(nyq, a, grid, lds_pad, st);
-            else launch_fast<1, 2>(nyq, a, grid, lds_pad, st);
+            if (nk == 0) launch_fast<1, 0>(nyq, depth, a, grid, lds_pad, st);
+            else if (nk == 1) launch_fast<1, 1>(nyq, depth, a, grid, lds_pad, st);
+            else launch_fast<1, 2>(nyq, depth, a, grid, lds_pad, st);
         }
         bd_set_last_kernel("bd_spectrum_band_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");

@@ -7,7 +7,7 @@ the store modes of that build (BD_SPEC_STORE):
   0 nt sc1 (the product's policy)   1 default   2 nt   3 sc1   4 nt sc0 sc1   5 sc0 sc1   6 sc0
   7 = mode 0 without the decisions either   8 = mode 0, values into one 1 MiB window
 With BEATDET_LIB=...exp_run512.so the variants are run lengths (BD_SPEC_RUN 128 / 256 / 512).
-Usage: exp_store.py modes 0,1,2 | runs 128,256,512      (environment: EXP_STREAMS, EXP_REPS, EXP_ROUNDS)"""
+Usage: exp_store.py modes 0,1,2 | runs 128,256,512 | grid 0:128,64000:128:3 (pad:run[:depth])      (environment: EXP_STREAMS, EXP_REPS, EXP_ROUNDS)"""
 import os
 import sys
 
@@ -42,11 +42,15 @@ def t(with_values):
 
 
 what, items = sys.argv[1], sys.argv[2].split(",")
-knob = {"modes": "spec_store", "runs": "spec_run"}[what]
 print(f"lib {bd.lib_path()}  {streams} streams x 60 s, L = {L}, {reps} launches per measurement", flush=True)
 for r in range(rounds):
     row = []
     for it in items:
-        with bd.tuning(**{knob: it}):
-            row.append(f"{what[:-1]} {it}: values {t(True):.3f} / none {t(False):.3f} ms")
+        if what == "grid":      # pad:run pairs (unused dynamic LDS in bytes : half-blocks per wavefront task)
+            pad, run, depth = (it.split(":") + ["0"])[:3]
+            knobs = {"spec_lds_pad": pad, "spec_run": run, "spec_depth": depth}
+        else:
+            knobs = {{"modes": "spec_store", "runs": "spec_run"}[what]: it}
+        with bd.tuning(**knobs):
+            row.append(f"{what[:-1] if what != 'grid' else 'pad:run'} {it}: values {t(True):.3f} / none {t(False):.3f} ms")
     print(f"round {r}: " + " | ".join(row), flush=True)
