@@ -229,19 +229,62 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int q_cb = (int)a.q;
 
     // ---- what a lane's place inside its callback fixes, once ----
-    unsigned mask[4];    // dword d of the masked piece holds samples GROUP PL + 8 l + 2 d, + 1
-    const int o_last = GROUP * PL + 8 * l;
-    // a masked piece that lies past the callback reads the lane's first piece instead
-    const int off_last = o_last < (int)L ? o_last : 8 * l;
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-        mask[d] = (o_last + 2 * d + 1 < (int)L) ? 0xffffffffu : ((o_last + 2 * d < (int)L) ? 0x0000ffffu : 0u);
-    const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
-    const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
-    // the head ends inside group PSTAR: there the lanes below `lstar` lie entirely inside it
+    // ALD (every kernel that does not stage): a row is loaded from the 16-byte line that holds its first
+    // sample, so all loads are aligned whatever the callback length; the row then starts `s` samples
+    // (0 .. 7) into the lane grid: lane l, piece p holds the samples 128 p + 8 l - s + m.  The s samples
+    // before the row (the previous callback's last ones, in lane 0's first piece) are masked out, the
+    // shift goes into the lane's rotation w^{k (8 l - s)}, and the cut at the end of the head and the
+    // end of the callback move by s lane positions.  Rows four callbacks apart are 8 L bytes apart: s
+    // is the same in every iteration for even L and alternates between s and s ^ 4 for odd L, so a
+    // lane needs two sets of constants, one per register buffer (buffer A serves every other iteration).
+    constexpr bool ALD = !STAGED;
+    static_assert(!ALD || LPC == 16, "the narrow variants stage");
     const int c = (int)a.head_len;
-    const int lstar = (c - GROUP * PSTAR) >> 3;
-    const bool below = l < lstar;
+    struct lane_set {
+        float    lc1, ls1, lc2, ls2;   // w^{k (8 l - s)}
+        unsigned first[4];             // keep-masks of the first piece's dwords (ALD: samples before the row)
+        unsigned mask[4];              // keep-masks of the masked last piece's dwords
+        int      off_last;             // where that piece is read (a piece past the callback: the lane's first piece)
+        unsigned below_mask;           // all ones if this lane's piece of group PSTAR lies entirely inside the head
+        bool     at_cut;               // this lane's piece of group PSTAR holds the cut
+    };
+    auto make_set = [&](int sh) {
+        lane_set k;
+        if (ALD) {
+            const int i1 = (8 * l - sh) & (BD_RING_LEN - 1), i2 = (2 * (8 * l - sh)) & (BD_RING_LEN - 1);
+            k.lc1 = bd_cos1024[i1]; k.ls1 = bd_sin1024[i1];
+            k.lc2 = bd_cos1024[i2]; k.ls2 = bd_sin1024[i2];
+        } else {
+            k.lc1 = BD_LANE_C[0][l]; k.ls1 = BD_LANE_S[0][l];
+            k.lc2 = BD_LANE_C[1][l]; k.ls2 = BD_LANE_S[1][l];
+        }
+        // dword d of the masked piece holds grid positions GROUP PL + 8 l + 2 d, + 1: samples at those minus sh
+        const int o_last = GROUP * PL + 8 * l;
+        k.off_last = o_last - sh < (int)L ? o_last : 8 * l;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            k.mask[d] = (o_last + 2 * d + 1 - sh < (int)L) ? 0xffffffffu : ((o_last + 2 * d - sh < (int)L) ? 0x0000ffffu : 0u);
+            k.first[d] = (8 * l + 2 * d >= sh) ? 0xffffffffu : ((8 * l + 2 * d + 1 >= sh) ? 0xffff0000u : 0u);
+        }
+        // the head ends inside group PSTAR: there the lanes below `lstar` lie entirely inside it
+        const int lstar = (c + sh - GROUP * PSTAR) >> 3;
+        k.below_mask = l < lstar ? 0xffffffffu : 0u;
+        k.at_cut = l == lstar;
+        // (the masks are made opaque: the compiler would otherwise recompute them from their
+        // comparisons inside the loop, as v_cndmask_b32)
+#pragma unroll
+        for (int d = 0; d < 4; d++) asm volatile("" : "+v"(k.mask[d]), "+v"(k.first[d]));
+        asm volatile("" : "+v"(k.below_mask));
+        return k;
+    };
+    // shift of callback j's row (samples): where its first sample sits in its 16-byte line
+    auto shift_of = [&](int64_t j) -> int {
+        return ALD ? (int)((((uintptr_t)sp + (uintptr_t)(j * L * 2)) & 15) >> 1) : 0;
+    };
+    const int64_t ja = j0 + ROWS * (int64_t)(j0 > 0 ? -1 : 0) + g;      // this lane's row in the first iteration
+    const lane_set KA = make_set(shift_of(ja)), KB = make_set(shift_of(ja + ROWS));
+    const int o_last = GROUP * PL + 8 * l;   // (staged kernels: grid position of the lane's last piece)
+    const int off_last = KA.off_last;
 
     const int64_t j_last = j0 + n_win - 1;
     // The staged copy counts bytes from `run_ptr`, the 16-byte line that holds the first sample this
@@ -258,6 +301,9 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int first_rel = (int)(j0 - cb0), last_rel = (int)(j_last - cb0);   // the run's callbacks, counted from cb0
     uint4 A[NBUF];
     uint4 B[STAGED ? 1 : NBUF];
+    const int it_first = it_begin;
+    const int64_t run_base = (int64_t)(s * a.stride) + j0 * L;   // the run's first sample, counted from a.samples
+    const int run_lo = (int)(((((uintptr_t)a.samples & 15) >> 1) + (uint64_t)run_base) & 7);   // its place in its 16-byte line
     auto load = [&](uint4 (&d)[NBUF], int it) {
         if (STAGED) {
             // callbacks jb .. jb + ROWS - 1 (those up to j_last) as 16-byte units from the unit that holds
@@ -281,31 +327,33 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 d[i] = bd_load_stream16(bp + (off < last_off ? off : last_off));
             }
         } else {
-            int64_t jj = j0 + ROWS * (int64_t)it + g;
-            jj = jj < j_last ? jj : j_last;                     // stand-in rows of the last iteration
+            // the row, counted from the run's first callback (32-bit arithmetic per lane)
+            int jr = ROWS * it + g;
+            jr = jr < n_win - 1 ? jr : n_win - 1;               // stand-in rows of the last iteration
             // before the run: only the q callbacks that its first rings reach into; the rows before them
             // repeat the first of those (no load sits under a lane predicate: the wait for this buffer
             // would otherwise have to be a wait for every load in flight)
-            jj = jj < j0 - q_cb ? j0 - q_cb : jj;
-            const int16_t *cp = sp + jj * L;
+            jr = jr < -q_cb ? -q_cb : jr;
+            // the 16-byte line that holds the row's first sample; lane positions count from there
+            // (the address stays an offset from the kernel's argument: global loads, not flat ones)
+            const int rel = jr * (int)L;                                        // samples from the run's first callback
+            const int back = (run_lo + rel) & 7;                                // the row's shift, in samples
+            const int16_t *cp = a.samples + run_base + (rel - back);
+            const int ol = (it - it_first) & 1 ? KB.off_last : KA.off_last;
 #pragma unroll
-            for (int p = 0; p < PIECES; p++) {
-                const bd_u32x4_a2 v = __builtin_nontemporal_load(
-                    reinterpret_cast<const bd_u32x4_a2 *>(cp + (p < PL ? GROUP * p + 8 * l : off_last)));
-                d[p] = make_uint4(v.x, v.y, v.z, v.w);
-            }
+            for (int p = 0; p < PIECES; p++)
+                d[p] = bd_load_stream16(cp + (p < PL ? GROUP * p + 8 * l : ol));
             if (REM) {
                 // the remainder's units in the row's first lanes (they may reach into the next callback,
                 // which exists); the other lanes repeat the last of them
                 const int lr = l < REM_UNITS ? l : REM_UNITS - 1;
-                const bd_u32x4_a2 v = __builtin_nontemporal_load(
-                    reinterpret_cast<const bd_u32x4_a2 *>(cp + GROUP * PL + 8 * lr));
-                d[NBUF - 1] = make_uint4(v.x, v.y, v.z, v.w);
+                d[NBUF - 1] = bd_load_stream16(cp + GROUP * PL + 8 * lr);
             }
         }
     };
     using TW = bd_split_tw<LPC>;
-    auto compute = [&](const auto &d, int it) {
+    auto compute = [&](const auto &d, int it, const lane_set &K) {
+        const float lc1 = K.lc1, ls1 = K.ls1, lc2 = K.lc2, ls2 = K.ls2;
         bd_split_acc x;
         x.a1 = x.b1 = x.a2 = x.b2 = 0.f; x.dc = 0;
         bd_split_acc h_before = x, h_after = x;   // accumulators before / after the pieces of group PSTAR
@@ -316,7 +364,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             const unsigned w[4] = {d[p].x, d[p].y, d[p].z, d[p].w};
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
-                const int v = (int)(p < PL ? w[qq] : (w[qq] & mask[qq]));
+                const int v = (int)(p < PL ? ((ALD && p == 0) ? (w[qq] & K.first[qq]) : w[qq]) : (w[qq] & K.mask[qq]));
                 const float x0 = (float)(short)(v & 0xffff);
                 const float x1 = (float)(short)(v >> 16);
                 const int i0 = 8 * p + 2 * qq, i1 = i0 + 1;   // table entry of sample GROUP p + 2 qq (+ 1)
@@ -334,10 +382,16 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             if (p == PSTAR) h_after = x;
         }
         // the pieces of this lane that lie entirely inside the head
+        // (selected bit by bit with the lane's mask: one v_bfi_b32 each; a v_cndmask_b32 occupies the SIMD
+        // several times as long)
         bd_split_acc h;
-        h.a1 = below ? h_after.a1 : h_before.a1; h.b1 = below ? h_after.b1 : h_before.b1;
-        h.a2 = below ? h_after.a2 : h_before.a2; h.b2 = below ? h_after.b2 : h_before.b2;
-        h.dc = below ? h_after.dc : h_before.dc;
+        const unsigned bm = K.below_mask;
+        auto pick = [bm](float x, float y) {   // x where the lane is below the cut, else y
+            return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, x) & bm) | (__builtin_bit_cast(unsigned, y) & ~bm));
+        };
+        h.a1 = pick(h_after.a1, h_before.a1); h.b1 = pick(h_after.b1, h_before.b1);
+        h.a2 = pick(h_after.a2, h_before.a2); h.b2 = pick(h_after.b2, h_before.b2);
+        h.dc = (int)(((unsigned)h_after.dc & bm) | ((unsigned)h_before.dc & ~bm));
         // (a + i b) w^{8 k l}: sums anchored at the callback's first sample
         bd_split_slot r;
         r.re1 = r.im1 = r.re2 = r.im2 = r.hre1 = r.him1 = r.hre2 = r.him2 = 0.f;
@@ -361,7 +415,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         asm volatile("" :: "v"(r.dc), "v"(r.hdc), "v"(r.amax));
         const int slot = ROWS * it + g + ROWS;   // callback j0 - ROWS + slot
         if (l == 0) slots[slot] = r;
-        if (l == lstar) keep[slot][0] = d[PSTAR];     // the piece that straddles the end of the head
+        if (K.at_cut) keep[slot][0] = d[PSTAR];       // the piece that straddles the end of the head
     };
     // (the scheduling barriers keep the next iteration's loads ahead of this iteration's arithmetic)
     if constexpr (STAGED) {
@@ -409,7 +463,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 pc[p].z = __builtin_amdgcn_alignbit(raw[p].v.w, raw[p].v.z, sh);
                 pc[p].w = __builtin_amdgcn_alignbit(raw[p].e, raw[p].v.w, sh);
             }
-            compute(pc, it);
+            compute(pc, it, KA);
             if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = pc[NPC - 1];
         };
         // P, Q: pieces of the iteration at hand and of the next one, as read from the staged copy
@@ -436,8 +490,8 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             if (++it >= n_it) break;
         }
     } else {
-        auto run = [&](const uint4 (&d)[NBUF], int it) {
-            compute(d, it);
+        auto run = [&](const uint4 (&d)[NBUF], int it, const lane_set &K) {
+            compute(d, it, K);
             if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = d[NBUF - 1];
         };
         int it = it_begin;
@@ -445,18 +499,18 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         for (; it + 2 < n_it; it += 2) {
             load(B, it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            run(A, it);
+            run(A, it, KA);
             load(A, it + 2);
             __builtin_amdgcn_sched_barrier(0);
-            run(B, it + 1);
+            run(B, it + 1, KB);
         }
         if (it + 1 < n_it) {
             load(B, it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            run(A, it);
-            run(B, it + 1);
+            run(A, it, KA);
+            run(B, it + 1, KB);
         } else {
-            run(A, it);
+            run(A, it, KA);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -469,9 +523,11 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             bd_split_acc y;
             y.a1 = y.b1 = y.a2 = y.b2 = 0.f; y.dc = 0;
             float ramax = 0.f;
-            bd_split_partial<NK, REM_UNITS>(keep[sidx] + 1, (int)L - GROUP * PL, y, ramax);
-            bd_rot(y.a1, y.b1, 1 * GROUP * PL);
-            bd_rot(y.a2, y.b2, 2 * GROUP * PL);
+            // parked from grid position GROUP PL of the row, that is from sample GROUP PL - sh
+            const int sh = shift_of(j0 - ROWS + sidx);
+            bd_split_partial<NK, REM_UNITS>(keep[sidx] + 1, (int)L - GROUP * PL + sh, y, ramax);
+            bd_rot(y.a1, y.b1, 1 * (GROUP * PL - sh));
+            bd_rot(y.a2, y.b2, 2 * (GROUP * PL - sh));
             bd_split_slot S = slots[sidx];
             S.re1 += y.a1; S.im1 += y.b1; S.re2 += y.a2; S.im2 += y.b2; S.dc += y.dc;
             S.amax = fmaxf(S.amax, ramax);
@@ -492,8 +548,10 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         const int64_t jt = jj - q;                          // the callback whose tail opens the ring
         if (jt >= 0 && t > 0) {
             const bd_split_slot T = slots[i + ROWS - q];
-            // the piece that straddles the cut: its first m samples belong to the head
-            const int m = c & 7;
+            // the piece that straddles the cut (grid position c + sh of that row): its first m samples
+            // belong to the head
+            const int sh = shift_of(jt);
+            const int m = (c + sh) & 7;
             bd_split_acc hh;
             hh.a1 = hh.b1 = hh.a2 = hh.b2 = 0.f; hh.dc = 0;
             float unused = 0.f;
@@ -569,10 +627,17 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     const bool narrow = callback_len < 384, narrow4 = callback_len < 128;
     const int group = narrow4 ? 32 : (narrow ? 64 : 128);
     const int pstar = (int)(a.head_len / group), pl = (int)(callback_len / group);
-    const bool rem = !narrow && (int)callback_len - group * pl <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
-    // the narrow variants always stage (a row of 4 or 8 lanes loads only 64 or 128 contiguous bytes per
-    // instruction: 100 samples 3.0 -> 3.5 TB/s, 300 4.6 -> 5.2 with the staged copy's whole-line loads)
-    const bool staged = narrow || (callback_len % 4 != 0 && !bd_tuning_get().split_no_stage);
+    const int rem_len = (int)callback_len - group * pl;      // samples past the last whole group
+    // Sixteen lanes per callback: rows are loaded from the 16-byte line that holds their first sample
+    // (all loads aligned; the row starts up to 7 samples into the lane grid) unless a shift by 7 samples
+    // would move the end of the head or of the callback into another group of 128, or the head is shorter
+    // than one piece; those lengths, and every narrow variant, go through the staged copy (a row of 4 or 8
+    // lanes loads only 64 or 128 contiguous bytes per instruction: 100 samples 3.0 -> 3.5 TB/s, 300
+    // 4.6 -> 5.2 with the staged copy's whole-line loads).
+    const bool ald = !narrow && a.head_len >= 8 && a.head_len % 128 <= 120 && rem_len <= 120 &&
+                     !bd_tuning_get().split_force_stage;
+    const bool staged = !ald;
+    const bool rem = !narrow && rem_len + (ald ? 7 : 0) <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
