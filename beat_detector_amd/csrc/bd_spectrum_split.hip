@@ -177,6 +177,53 @@ template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
     }
 }
 
+// Row reductions of the sixteen-lane kernel, all at once.  A DPP instruction writes only the quads of a row that its
+// bank mask names, so one register can carry the partial sums of several quantities side by side:
+//   level 1 (lane l + lane l ^ 8): quantity A in the lower half of the row, B in the upper half     2 instructions per pair
+//   level 2 (lane l + lane 7 - l of its half): pairs (A, B) and (C, D) into one register, A C B D by quad     2 per four
+//   levels 3, 4 (inside the quad): 2 per register, whatever it carries
+// Eight float sums cost 16 instructions instead of 32, the two integer sums 5 instead of 8, the maximum 4.
+// Results: s1 = sums of (a, c, b, d) in quads (0, 1, 2, 3) of the row, s2 the same of (e, g, f, h); t = sum of ia in the
+// row's lower half, of ib in its upper half; mx = maximum of m, in every lane.
+// (One assembly statement: the compiler does not give DPP instructions a bank mask.  A DPP operand must have been
+// written at least two instructions earlier: the order below keeps that distance, the s_nop covers the inputs.)
+__device__ __forceinline__ void bd_split_reduce16(float a, float b, float c, float d, float e, float f, float g, float h,
+                                                  int ia, int ib, float m, float &s1, float &s2, int &t, float &mx)
+{
+    float r1, r2, r3, r4;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %[r1], %[a], %[a] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[r1], %[b], %[b] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r2], %[c], %[c] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[r2], %[d], %[d] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r3], %[e], %[e] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[r3], %[f], %[f] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %[r4], %[g], %[g] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %[r4], %[h], %[h] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_u32_dpp %[t], %[ia], %[ia] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_u32_dpp %[t], %[ib], %[ib] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_max_f32_dpp %[mx], %[m], %[m] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[r1], %[r1] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[s2], %[r3], %[r3] row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %[s1], %[r2], %[r2] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %[s2], %[r4], %[r4] row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_u32_dpp %[t], %[t], %[t] row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %[mx], %[mx], %[mx] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[s1], %[s1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s2], %[s2], %[s2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %[t], %[t], %[t] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %[mx], %[mx], %[mx] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s1], %[s1], %[s1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %[s2], %[s2], %[s2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_u32_dpp %[t], %[t], %[t] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %[mx], %[mx], %[mx] row_ror:1 row_mask:0xf bank_mask:0xf"
+        : [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3), [r4] "=&v"(r4), [s1] "=&v"(s1), [s2] "=&v"(s2), [t] "=&v"(t),
+          [mx] "=&v"(mx)
+        : [a] "v"(a), [b] "v"(b), [c] "v"(c), [d] "v"(d), [e] "v"(e), [f] "v"(f), [g] "v"(g), [h] "v"(h), [ia] "v"(ia),
+          [ib] "v"(ib), [m] "v"(m));
+}
+
 // PSTAR: index of the group of GROUP samples that holds the end of the head (head_len / GROUP).
 // PL: index of the group that holds the end of the callback (callback_len / GROUP): the groups
 // before it are whole in every lane, the groups after it are not read at all.
@@ -194,7 +241,8 @@ template <int LPC> __device__ __forceinline__ float bd_group_max(float v)
 // samples and more; 8 (groups of 64 samples, eight callbacks per iteration) for 129 .. 383 samples, whose
 // ring spans up to seven whole callbacks; 4 (groups of 32 samples, sixteen callbacks per iteration) for
 // 65 .. 127 samples: up to fifteen whole callbacks.
-template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16>
+// SH: rows are read on the grid of 16-byte lines (see the comment at `lane_set` below).
+template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16, bool SH = !STAGED>
 __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_split_kernel(bd_split_args a)
 {
     constexpr int WAVES = bd_split_waves(STAGED, REM);
@@ -229,20 +277,22 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int q_cb = (int)a.q;
 
     // ---- what a lane's place inside its callback fixes, once ----
-    // ALD (every kernel that does not stage): a row is loaded from the 16-byte line that holds its first
-    // sample, so all loads are aligned whatever the callback length; the row then starts `s` samples
-    // (0 .. 7) into the lane grid: lane l, piece p holds the samples 128 p + 8 l - s + m.  The s samples
-    // before the row (the previous callback's last ones, in lane 0's first piece) are masked out, the
-    // shift goes into the lane's rotation w^{k (8 l - s)}, and the cut at the end of the head and the
-    // end of the callback move by s lane positions.  Rows four callbacks apart are 8 L bytes apart: s
-    // is the same in every iteration for even L and alternates between s and s ^ 4 for odd L, so a
-    // lane needs two sets of constants, one per register buffer (buffer A serves every other iteration).
+    // SH: a row is read from the 16-byte line that holds its first sample -- of memory (the kernels that do
+    // not stage: all global loads aligned, whatever the callback length) or of the staged copy (aligned
+    // 16-byte LDS reads, no funnel shift) -- so the row starts `s` samples (0 .. 7) into the lane grid: lane
+    // l, piece p holds the samples 128 p + 8 l - s + m.  The s samples before the row (the previous
+    // callback's last ones, in lane 0's first piece) are masked out, the shift goes into the lane's
+    // rotation w^{k (8 l - s)}, and the cut at the end of the head and the end of the callback move by s
+    // lane positions.  Rows four callbacks apart are 8 L bytes apart: s is the same in every iteration for
+    // even L and alternates between s and s ^ 4 for odd L, so a lane needs two sets of constants, one per
+    // register buffer (each buffer serves every other iteration).
     constexpr bool ALD = !STAGED;
-    static_assert(!ALD || LPC == 16, "the narrow variants stage");
+    static_assert(!ALD || (LPC == 16 && SH), "the narrow variants stage; unstaged rows are read on the line grid");
+    static_assert(!SH || LPC == 16, "the line grid is for sixteen lanes per callback");
     const int c = (int)a.head_len;
     struct lane_set {
         float    lc1, ls1, lc2, ls2;   // w^{k (8 l - s)}
-        unsigned first[4];             // keep-masks of the first piece's dwords (ALD: samples before the row)
+        unsigned first[4];             // keep-masks of the first piece's dwords (SH: samples before the row)
         unsigned mask[4];              // keep-masks of the masked last piece's dwords
         int      off_last;             // where that piece is read (a piece past the callback: the lane's first piece)
         unsigned below_mask;           // all ones if this lane's piece of group PSTAR lies entirely inside the head
@@ -250,7 +300,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     };
     auto make_set = [&](int sh) {
         lane_set k;
-        if (ALD) {
+        if (SH) {
             const int i1 = (8 * l - sh) & (BD_RING_LEN - 1), i2 = (2 * (8 * l - sh)) & (BD_RING_LEN - 1);
             k.lc1 = bd_cos1024[i1]; k.ls1 = bd_sin1024[i1];
             k.lc2 = bd_cos1024[i2]; k.ls2 = bd_sin1024[i2];
@@ -279,7 +329,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     };
     // shift of callback j's row (samples): where its first sample sits in its 16-byte line
     auto shift_of = [&](int64_t j) -> int {
-        return ALD ? (int)((((uintptr_t)sp + (uintptr_t)(j * L * 2)) & 15) >> 1) : 0;
+        return SH ? (int)((((uintptr_t)sp + (uintptr_t)(j * L * 2)) & 15) >> 1) : 0;
     };
     const int64_t ja = j0 + ROWS * (int64_t)(j0 > 0 ? -1 : 0) + g;      // this lane's row in the first iteration
     const lane_set KA = make_set(shift_of(ja)), KB = make_set(shift_of(ja + ROWS));
@@ -364,7 +414,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             const unsigned w[4] = {d[p].x, d[p].y, d[p].z, d[p].w};
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
-                const int v = (int)(p < PL ? ((ALD && p == 0) ? (w[qq] & K.first[qq]) : w[qq]) : (w[qq] & K.mask[qq]));
+                const int v = (int)(p < PL ? ((SH && p == 0) ? (w[qq] & K.first[qq]) : w[qq]) : (w[qq] & K.mask[qq]));
                 const float x0 = (float)(short)(v & 0xffff);
                 const float x1 = (float)(short)(v >> 16);
                 const int i0 = 8 * p + 2 * qq, i1 = i0 + 1;   // table entry of sample GROUP p + 2 qq (+ 1)
@@ -393,6 +443,26 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         h.a2 = pick(h_after.a2, h_before.a2); h.b2 = pick(h_after.b2, h_before.b2);
         h.dc = (int)(((unsigned)h_after.dc & bm) | ((unsigned)h_before.dc & ~bm));
         // (a + i b) w^{8 k l}: sums anchored at the callback's first sample
+        const int slot = ROWS * it + g + ROWS;   // callback j0 - ROWS + slot
+        if constexpr (LPC == 16 && NK == 2) {
+            // All eleven row reductions in one network (bd_split_reduce16): 25 lane-crossing instructions
+            // instead of 44.  The sums come out spread over the row's quads; the first lane of each quad
+            // stores its share of the slot.
+            float s1, s2, mx;
+            int t;
+            bd_split_reduce16(x.a1 * lc1 - x.b1 * ls1, x.a1 * ls1 + x.b1 * lc1, x.a2 * lc2 - x.b2 * ls2, x.a2 * ls2 + x.b2 * lc2,
+                              h.a1 * lc1 - h.b1 * ls1, h.a1 * ls1 + h.b1 * lc1, h.a2 * lc2 - h.b2 * ls2, h.a2 * ls2 + h.b2 * lc2,
+                              x.dc, h.dc, amax, s1, s2, t, mx);
+            if ((l & 3) == 0) {
+                const int qd = l >> 2;                       // quad 0: re1 / hre1, 1: re2 / hre2, 2: im1 / him1, 3: im2 / him2
+                const int f = (qd & 1) * 2 + (qd >> 1);
+                float *sf = reinterpret_cast<float *>(&slots[slot]);
+                sf[f] = s1;
+                sf[4 + f] = s2;
+                reinterpret_cast<int *>(sf)[8 + (qd >> 1)] = t;   // lower half of the row: dc, upper half: hdc
+                sf[10] = mx;
+            }
+        } else {
         bd_split_slot r;
         r.re1 = r.im1 = r.re2 = r.im2 = r.hre1 = r.him1 = r.hre2 = r.him2 = 0.f;
         if (NK >= 1) {
@@ -413,8 +483,8 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1), "v"(r.hre1), "v"(r.him1));
         if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2), "v"(r.hre2), "v"(r.him2));
         asm volatile("" :: "v"(r.dc), "v"(r.hdc), "v"(r.amax));
-        const int slot = ROWS * it + g + ROWS;   // callback j0 - ROWS + slot
         if (l == 0) slots[slot] = r;
+        }
         if (K.at_cut) keep[slot][0] = d[PSTAR];       // the piece that straddles the end of the head
     };
     // (the scheduling barriers keep the next iteration's loads ahead of this iteration's arithmetic)
@@ -441,29 +511,37 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             // byte offset of the row's first sample inside the staged copy
             const unsigned row_off = ((m0 + (unsigned)jb * L2) & 15) + (unsigned)(jj - jb) * L2;
             const unsigned sh = (row_off & 2) ? 16u : 0u;
-            const char *sb = reinterpret_cast<const char *>(stage) + (row_off & ~3u);
+            // SH: whole 16-byte units of the copy from the one that holds the row's first sample (the copy
+            // starts on a 16-byte line of memory); otherwise five dwords from the one below the piece
+            const char *sb = reinterpret_cast<const char *>(stage) + (row_off & (SH ? ~15u : ~3u));
+            const int ol = (it - it_first) & 1 ? KB.off_last : KA.off_last;
 #pragma unroll
             for (int p = 0; p < NPC; p++) {
                 if (p == PIECES && l >= REM_UNITS) break;   // the remainder's units: the row's first lanes
-                const unsigned po = (unsigned)(2 * (p < PL ? GROUP * p + 8 * l : (REM ? o_last : off_last)));
-                typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-                const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(sb + po);
-                pc[p].v = make_uint4(v.x, v.y, v.z, v.w);
-                pc[p].e = *reinterpret_cast<const unsigned *>(sb + po + 16);
+                const unsigned po = (unsigned)(2 * (p < PL ? GROUP * p + 8 * l : (REM ? o_last : (SH ? ol : off_last))));
+                if (SH) {
+                    pc[p].v = *reinterpret_cast<const uint4 *>(sb + po);
+                } else {
+                    typedef unsigned int u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+                    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(sb + po);
+                    pc[p].v = make_uint4(v.x, v.y, v.z, v.w);
+                    pc[p].e = *reinterpret_cast<const unsigned *>(sb + po + 16);
+                }
             }
             pc[0].sh = sh;
         };
-        auto sums = [&](const raw_piece (&raw)[NPC], int it) {
+        auto sums = [&](const raw_piece (&raw)[NPC], int it, const lane_set &K) {
             const unsigned sh = raw[0].sh;
             uint4 pc[NPC];
 #pragma unroll
             for (int p = 0; p < NPC; p++) {
+                if (SH) { pc[p] = raw[p].v; continue; }
                 pc[p].x = __builtin_amdgcn_alignbit(raw[p].v.y, raw[p].v.x, sh);
                 pc[p].y = __builtin_amdgcn_alignbit(raw[p].v.z, raw[p].v.y, sh);
                 pc[p].z = __builtin_amdgcn_alignbit(raw[p].v.w, raw[p].v.z, sh);
                 pc[p].w = __builtin_amdgcn_alignbit(raw[p].e, raw[p].v.w, sh);
             }
-            compute(pc, it, KA);
+            compute(pc, it, K);
             if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = pc[NPC - 1];
         };
         // P, Q: pieces of the iteration at hand and of the next one, as read from the staged copy
@@ -483,10 +561,10 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         pick(P, it);
         for (;;) {
             advance(Q, it);
-            sums(P, it);
+            sums(P, it, KA);
             if (++it >= n_it) break;
             advance(P, it);
-            sums(Q, it);
+            sums(Q, it, KB);
             if (++it >= n_it) break;
         }
     } else {
@@ -588,6 +666,17 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     }
 }
 
+// Callback lengths that run faster with rows loaded straight from memory than through the staged copy:
+// those whose remainder past the last whole group of 128 is short enough to be parked (at most 17 samples,
+// so the direct kernel has no masked piece).  Measured at 16,384 streams x 60 s, direct / staged: 385 5.43 /
+// 5.21 TB/s, 400 5.58 / 5.32, 517 5.78 / 5.66, 529 5.96 / 5.69, 641 5.97 / 5.92; with a masked piece the
+// staged copy wins: 420 5.21 / 5.43, 441 5.38 / 5.52, 450 5.39 / 5.61, 500 5.86 / 6.05, 532 5.65 / 5.71,
+// 600 5.91 / 6.16, 700 5.86 / 6.18, 730 6.01 / 6.35.
+static bool bd_split_prefers_direct(uint32_t callback_len)
+{
+    return callback_len % 128 <= 17;
+}
+
 bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
 {
     // bins 0 .. 2, no Nyquist packing; lengths that 16 lanes x 24 .. 48 samples (8 lanes x 24 .. 32 below 256)
@@ -628,25 +717,29 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     const int group = narrow4 ? 32 : (narrow ? 64 : 128);
     const int pstar = (int)(a.head_len / group), pl = (int)(callback_len / group);
     const int rem_len = (int)callback_len - group * pl;      // samples past the last whole group
-    // Sixteen lanes per callback: rows are loaded from the 16-byte line that holds their first sample
-    // (all loads aligned; the row starts up to 7 samples into the lane grid) unless a shift by 7 samples
-    // would move the end of the head or of the callback into another group of 128, or the head is shorter
-    // than one piece; those lengths, and every narrow variant, go through the staged copy (a row of 4 or 8
-    // lanes loads only 64 or 128 contiguous bytes per instruction: 100 samples 3.0 -> 3.5 TB/s, 300
-    // 4.6 -> 5.2 with the staged copy's whole-line loads).
-    const bool ald = !narrow && a.head_len >= 8 && a.head_len % 128 <= 120 && rem_len <= 120 &&
-                     !bd_tuning_get().split_force_stage;
-    const bool staged = !ald;
-    const bool rem = !narrow && rem_len + (ald ? 7 : 0) <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
+    // Sixteen lanes per callback: rows are read on the grid of 16-byte lines (the row starts up to 7
+    // samples into the lane grid) unless a shift by 7 samples would move the end of the head or of the
+    // callback into another group of 128, or the head is shorter than one piece: those lengths, and the
+    // narrow variants, read the staged copy at 4-byte-aligned addresses and funnel-shift odd rows.
+    const bool sh = !narrow && a.head_len >= 8 && a.head_len % 128 <= 120 && rem_len <= 120;
+    // Staged copy (global -> LDS in whole contiguous lines, lanes pick their pieces there) or rows loaded
+    // straight from memory at 16-byte-aligned addresses (a row of 16 lanes then covers 256 contiguous bytes
+    // that straddle three 128-byte lines).  The narrow variants always stage (a row of 4 or 8 lanes would
+    // load only 64 or 128 contiguous bytes per instruction: 100 samples 3.0 -> 3.5 TB/s, 300 4.6 -> 5.2).
+    const int mode = bd_tuning_get().split_stage;          // experiment switch: 1 = always staged, 2 = direct where possible
+    const bool direct = sh && mode != 1 && (mode == 2 || bd_split_prefers_direct(callback_len));
+    const bool staged = !direct;
+    const bool rem = !narrow && rem_len + (sh ? 7 : 0) <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
 #define BD_SPLIT_GO(NK, PS, PLAST, RM, LANES) do { \
-        if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
-        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM, LANES>), grid, dim3(64 * waves), 0, st, a); \
+        if (staged && sh) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM, LANES, true>), grid, dim3(64 * waves), 0, st, a); \
+        else if (staged) hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, RM, LANES, false>), grid, dim3(64 * waves), 0, st, a); \
+        else hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, false, RM, LANES, true>), grid, dim3(64 * waves), 0, st, a); \
         launched = true; } while (0)
 #define BD_SPLIT_GO_ST(NK, PS, PLAST, LANES) do { \
-        hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, false, LANES>), grid, dim3(64 * waves), 0, st, a); \
+        hipLaunchKernelGGL((bd_spectrum_split_kernel<NK, PS, PLAST, true, false, LANES, false>), grid, dim3(64 * waves), 0, st, a); \
         launched = true; } while (0)
 #define BD_SPLIT_PICK(NK) do { \
         if (narrow4) { \
