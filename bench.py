@@ -139,6 +139,7 @@ def self_launch(n: int, wall_limit_s: float) -> int:
                 print(f"bench.py: rank {procs.index(p)} exited with {code}; ending the other ranks", file=sys.stderr)
                 end(pending)   # a rank failed: the others would wait at a barrier until its timeout
                 pending = []
+                break
         if pending and time.monotonic() > deadline:
             print(f"bench.py: {len(pending)} of {n} ranks still running after {wall_limit_s:.0f} s "
                   "(--launch-timeout); ending them", file=sys.stderr)
