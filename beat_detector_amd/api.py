@@ -168,6 +168,8 @@ def lib() -> C.CDLL:
         "bd_last_error": (C.c_char_p, []),
         "bd_device_count": (i32, [C.POINTER(i32)]),
         "bd_device_name": (i32, [i32, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]),
+        "bd_current_device": (i32, [C.POINTER(i32)]),
+        "bd_set_device": (i32, [i32]),
         "bd_kind_count": (i32, []),
         "bd_kind_name": (C.c_char_p, [i32]),
         "bd_kind_description": (C.c_char_p, [i32]),
@@ -229,7 +231,7 @@ def lib() -> C.CDLL:
 
 
 EXPORTED_SYMBOLS = (
-    "bd_default_params bd_strerror bd_last_error bd_device_count bd_device_name bd_kind_count bd_kind_name "
+    "bd_default_params bd_strerror bd_last_error bd_device_count bd_device_name bd_current_device bd_set_device bd_kind_count bd_kind_name "
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_noalloc bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "

@@ -63,6 +63,20 @@ extern "C" int bd_device_count(int *count)
     return BD_OK;
 }
 
+extern "C" int bd_current_device(int *device)
+{
+    if (!device) { bd_set_error("bd_current_device: device is NULL"); return BD_ERR_INVALID_ARG; }
+    return bd_check_hip(hipGetDevice(device), "hipGetDevice");
+}
+
+extern "C" int bd_set_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (device < 0 || device >= n) { bd_set_error("bd_set_device: no GPU with index %d", device); return BD_ERR_NO_DEVICE; }
+    return bd_check_hip(hipSetDevice(device), "hipSetDevice");
+}
+
 extern "C" int bd_device_name(int device, char *name, size_t capacity, uint64_t *total_memory_bytes)
 {
     if (!name || capacity == 0) { bd_set_error("bd_device_name: name buffer missing"); return BD_ERR_INVALID_ARG; }

@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // everything that selects the task is the same in all lanes: keep it scalar
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t task = bd_block_index() * 4 + wave;
-    if (task >= a.n_tasks) return;
+    if (task >= a.n_tasks) {
+        if (MODE == 0) __syncthreads();    // the block's other wavefronts meet at one barrier (below)
+        return;
+    }
     const uint64_t s = task / a.runs_per_stream;
     const uint32_t r = (uint32_t)(task - s * a.runs_per_stream);
     const int64_t hb0 = (int64_t)r * a.run_hbs;
@@ -214,9 +217,14 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // iterations of this run that contain at least one half-block of the stream
     const int64_t left = n_hb - hb0;
     const int n_it = (int)((left < (int64_t)a.run_hbs ? left + 3 : (int64_t)a.run_hbs) / 4);
-    // hop 512: the first callback of a run needs the half-block before the run
-    const int it_begin = (MODE == 0 && hb0 > 0) ? -1 : 0;
-    const int64_t hb_lo = (MODE == 0 && hb0 > 0) ? hb0 - 1 : hb0;   // first half-block the run reads
+    // hop 512: the first callback of a run needs the half-block before the run.  The four wavefronts of a
+    // block walk four consecutive runs, so three of them find that half-block's sums in their
+    // neighbour's LDS slots once the block has met at a barrier; only a block's first wavefront (and a
+    // stream's first run after another stream's last) reads the half-block again.
+    const bool from_neighbour = MODE == 0 && wave > 0 && r > 0;
+    const bool reread = MODE == 0 && hb0 > 0 && !from_neighbour;
+    const int it_begin = reread ? -1 : 0;
+    const int64_t hb_lo = reread ? hb0 - 1 : hb0;   // first half-block the run reads
 
     const float lc1 = BD_LANE_C[0][l], ls1 = BD_LANE_S[0][l];
     const float lc2 = BD_LANE_C[1][l], ls2 = BD_LANE_S[1][l];
@@ -270,6 +278,17 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // results of the run: consecutive lanes finish and store consecutive callbacks
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    if (MODE == 0) {
+        __syncthreads();                       // every wavefront of the block has parked its sums
+        if (from_neighbour && lane == 0) {
+            // the last half-block of the run before this one (a whole run: this is not its stream's first)
+            const int e = bd_spec_entry<MODE>((int)a.run_hbs);
+            slots->sums[0] = lds_slots[wave - 1].sums[e];
+            slots->misc[0] = lds_slots[wave - 1].misc[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     const uint64_t cb0 = (uint64_t)(hb0 >> MODE);
     const uint64_t cb_left = a.n_cb - cb0;
     const unsigned n_res_run = (unsigned)(n_it * (MODE == 0 ? 4 : 2));

@@ -139,6 +139,8 @@ extern "C" {
     pub fn bd_strerror(status: c_int) -> *const c_char;
     pub fn bd_last_error() -> *const c_char;
     pub fn bd_device_count(count: *mut c_int) -> c_int;
+    pub fn bd_current_device(device: *mut c_int) -> c_int;
+    pub fn bd_set_device(device: c_int) -> c_int;
     pub fn bd_device_name(device: c_int, name: *mut c_char, capacity: usize, total_memory_bytes: *mut u64) -> c_int;
 
     // StrategyKind metadata

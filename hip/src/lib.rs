@@ -56,8 +56,10 @@ impl BeatInfo {
 /// The per-window strategy interface (`src/lib.rs:72-137`).  The two shared
 /// gates of the parent trait (`last_beat_beyond_threshold`,
 /// `amplitude_high_enough`) take the parent's private `AnalysisState` /
-/// `WindowStats`; on the GPU they are part of the kernel, so they are not
-/// repeated here.
+/// `WindowStats`, so they cannot be provided methods here; on the GPU they are
+/// part of the kernel.  For strategies ported from the parent crate they exist
+/// as the free functions [`last_beat_beyond_threshold`] and
+/// [`amplitude_high_enough`] over the plain numbers those types hold.
 pub trait Strategy {
     /// `Some(BeatInfo)` if the callback's samples complete a beat.
     fn is_beat(&self, samples: &[i16]) -> Option<BeatInfo>;
@@ -76,6 +78,31 @@ pub trait Strategy {
     fn min_duration_between_beats_ms() -> u32
     where
         Self: Sized;
+}
+
+/// `Strategy::last_beat_beyond_threshold` (`src/lib.rs:115-127`) over the numbers an
+/// `AnalysisState` holds: `beat_time_ms` is the middle of the current callback on the
+/// detector's clock, `last_beat_ms` the time of the last beat (0 before the first),
+/// `min_duration_ms` the strategy's `min_duration_between_beats_ms()`.  `false` means the
+/// callback comes too soon after the last beat and cannot be one.
+#[inline(always)]
+pub const fn last_beat_beyond_threshold(beat_time_ms: u32, last_beat_ms: u32, min_duration_ms: u32) -> bool {
+    // only check this if at least a single beat was recognized
+    if beat_time_ms > 0 {
+        let threshold = last_beat_ms + min_duration_ms;
+        if beat_time_ms < threshold {
+            return false;
+        }
+    }
+    true
+}
+
+/// `Strategy::amplitude_high_enough` (`src/lib.rs:133-136`) over the number a `WindowStats`
+/// holds: the largest absolute sample of the callback (`window_stats.rs:41-55`).
+#[inline(always)]
+pub const fn amplitude_high_enough(max_amplitude: u16) -> bool {
+    const MIN_AMPLITUDE_THRESHOLD: i16 = (i16::MAX as f32 * 0.3) as i16;
+    max_amplitude >= MIN_AMPLITUDE_THRESHOLD as u16
 }
 
 /// `src/lib.rs:142-185`; discriminants follow `values()` and the C header.
@@ -297,8 +324,72 @@ pub fn analyze_batch(kind: StrategyKind, sampling_rate: u32, samples: &[i16], n_
     Ok(beat_lists(&count, &idx, &ms, max_beats as usize))
 }
 
-/// The same, sharded by stream over several GPUs of the node (contiguous
-/// shards, no traffic between GPUs).
+/// The batched entry point on memory that already lies on GPU `device`: `samples` is a device
+/// pointer to `n_streams` rows of `stream_stride` samples, `flags` a device buffer of `n_streams`
+/// rows of `n_samples / callback_len` bytes (the per-callback decisions, scratch for the caller),
+/// `beat_count` / `beat_idx` / `beat_ms` device arrays (`[n_streams]`, `[n_streams][max_beats]`).
+/// Only enqueues on `hip_stream` (null: the default stream) and allocates nothing: this is the
+/// entry for throughput (the kernels read at HBM speed), and the one a multi-GPU program calls from
+/// one thread or process per GPU with its own shard of the streams -- streams are independent, so no
+/// data crosses GPUs.  [`analyze_batch`] and [`analyze_batch_multi`] take host slices instead and are
+/// bounded by the copy over PCIe (about 30 GB/s per GPU, two orders of magnitude below the kernels).
+///
+/// # Safety
+/// Every pointer must be a device pointer of `device` with the extent described above, valid until
+/// the work enqueued on `hip_stream` has finished.
+#[allow(clippy::too_many_arguments)]
+pub unsafe fn analyze_batch_on(
+    device: i32,
+    kind: StrategyKind,
+    sampling_rate: u32,
+    samples: *const i16,
+    n_streams: u64,
+    n_samples: u64,
+    stream_stride: u64,
+    callback_len: u32,
+    flags: *mut u8,
+    beat_count: *mut u32,
+    beat_idx: *mut u32,
+    beat_ms: *mut u32,
+    max_beats: u32,
+    hip_stream: *mut std::os::raw::c_void,
+) -> Result<(), String> {
+    let mut prev: c_int = -1;
+    if ffi::bd_current_device(&mut prev) != ffi::BD_OK || ffi::bd_set_device(device as c_int) != ffi::BD_OK {
+        return Err(last_error());
+    }
+    let rc = ffi::bd_analyze_batch(
+        kind.as_raw(),
+        sampling_rate,
+        std::ptr::null(),
+        samples,
+        n_streams,
+        n_samples,
+        stream_stride,
+        callback_len,
+        std::ptr::null_mut(),
+        flags,
+        0,
+        beat_count,
+        beat_idx,
+        beat_ms,
+        max_beats,
+        hip_stream,
+    );
+    let message = if rc != ffi::BD_OK { last_error() } else { String::new() };
+    if prev >= 0 && prev != device as c_int {
+        ffi::bd_set_device(prev);
+    }
+    if rc != ffi::BD_OK {
+        return Err(message);
+    }
+    Ok(())
+}
+
+/// The host-slice entry sharded by stream over several GPUs of the node (contiguous shards, no
+/// traffic between GPUs).  Like [`analyze_batch`] it copies the samples over PCIe, which bounds
+/// it at about 30 GB/s per GPU; with samples already on the GPUs use [`analyze_batch_on`] per
+/// device instead.
 pub fn analyze_batch_multi(kind: StrategyKind, sampling_rate: u32, samples: &[i16], n_samples: usize, callback_len: u32, devices: &[i32]) -> Result<BeatLists, String> {
     if n_samples == 0 || samples.len() % n_samples != 0 {
         return Err("samples.len() must be a multiple of n_samples".to_string());
@@ -365,6 +456,34 @@ impl Live {
         let n = (samples.len() / self.n_streams) as u32;
         let mut tick = 0u64;
         let rc = unsafe { ffi::bd_live_submit(self.raw, samples.as_ptr() as *const _, n, ffi::BD_FMT_I16, &mut tick) };
+        if rc != ffi::BD_OK {
+            return Err(last_error());
+        }
+        let mut beats = vec![0u8; self.n_streams];
+        let mut ms = vec![0u32; self.n_streams];
+        let rc = unsafe { ffi::bd_live_poll(self.raw, tick, 1, beats.as_mut_ptr(), ms.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc < 0 {
+            return Err(last_error());
+        }
+        Ok(beats.iter().zip(ms.iter()).map(|(&b, &m)| if b != 0 { Some(BeatInfo::new(m)) } else { None }).collect())
+    }
+}
+
+impl Live {
+    /// One tick in which every stream brings its own number of `i16` samples
+    /// (`bd_live_submit_ragged`): in the parent every stream is a device of its own whose
+    /// closure gets its own `data.len()` (`src/record.rs:93-95,107-109,121-123`).  `samples`
+    /// is `[n_streams][row_pitch]`, stream `m`'s callback the first `lengths[m]` samples of
+    /// its row; a stream with length 0 skips the tick (its detector does not advance).
+    pub fn tick_ragged(&mut self, samples: &[i16], lengths: &[u32]) -> Result<Vec<Option<BeatInfo>>, String> {
+        if self.n_streams == 0 || lengths.len() != self.n_streams || samples.len() % self.n_streams != 0 {
+            return Err("samples must be [n_streams][row_pitch], lengths [n_streams]".to_string());
+        }
+        let pitch = (samples.len() / self.n_streams) as u32;
+        let mut tick = 0u64;
+        let rc = unsafe {
+            ffi::bd_live_submit_ragged(self.raw, samples.as_ptr() as *const _, lengths.as_ptr(), pitch, ffi::BD_FMT_I16, &mut tick)
+        };
         if rc != ffi::BD_OK {
             return Err(last_error());
         }

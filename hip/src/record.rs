@@ -57,9 +57,14 @@ pub trait InputDevice: Send + 'static {
     fn read(&mut self, buffer: &mut [u8]) -> usize;
 }
 
+/// What the two trampolines share.  Both only ever form a shared reference to it: the library's
+/// listening thread reads `keep_flag` through a raw pointer while they run, so no `&mut Context`
+/// may exist.  The one field that needs exclusive access, the device, sits in an `UnsafeCell`;
+/// only `read_trampoline` touches it, and the library calls the trampolines from its one listening
+/// thread, one after the other.
 struct Context<F: Fn(BeatInfo) + Send + 'static, D: InputDevice> {
     on_beat: F,
-    device: D,
+    device: std::cell::UnsafeCell<D>,
     bytes_per_sample: usize,
     keep: Arc<AtomicBool>,
     // the C side polls an int: the read trampoline mirrors the AtomicBool into it before every callback
@@ -72,14 +77,16 @@ unsafe extern "C" fn on_beat_trampoline<F: Fn(BeatInfo) + Send + 'static, D: Inp
 }
 
 unsafe extern "C" fn read_trampoline<F: Fn(BeatInfo) + Send + 'static, D: InputDevice>(user: *mut c_void, buffer: *mut c_void, capacity: usize) -> usize {
-    let ctx = &mut *(user as *mut Context<F, D>);
+    let ctx = &*(user as *const Context<F, D>);
     // the stop flag is sampled once per callback (`src/record.rs:141-145` polls it in a loop)
     if !ctx.keep.load(Ordering::SeqCst) {
         ctx.keep_flag.store(0, Ordering::SeqCst);
         return 0;
     }
     let bytes = std::slice::from_raw_parts_mut(buffer as *mut u8, capacity * ctx.bytes_per_sample);
-    ctx.device.read(bytes).min(capacity)
+    // exclusive by construction: nothing else reads or writes the device (see `Context`)
+    let device = &mut *ctx.device.get();
+    device.read(bytes).min(capacity)
 }
 
 /// Starts listening on `input_dev` and calls `on_beat_cb` on each recognised
@@ -115,7 +122,7 @@ fn start<F: Fn(BeatInfo) + Send + 'static, D: InputDevice>(
     eprintln!("  sample_format: {:?}", format);
     let ctx = Box::new(Context {
         on_beat: on_beat_cb,
-        device,
+        device: std::cell::UnsafeCell::new(device),
         bytes_per_sample: format.bytes_per_sample(),
         keep: keep_recording,
         keep_flag: std::sync::atomic::AtomicI32::new(1),
@@ -135,7 +142,8 @@ fn start<F: Fn(BeatInfo) + Send + 'static, D: InputDevice>(
             ctx_ptr as *mut c_void,
             &source,
             strategy.as_raw(),
-            &(*ctx_ptr).keep_flag as *const std::sync::atomic::AtomicI32 as *const c_int,
+            // (field address taken without forming a reference to the whole context)
+            std::ptr::addr_of!((*ctx_ptr).keep_flag) as *const c_int,
             &mut listener,
         )
     };

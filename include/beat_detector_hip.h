@@ -74,6 +74,14 @@ const char *bd_last_error(void);
 /* Number of visible GPUs (0 and BD_OK when there is none). */
 int bd_device_count(int *count);
 
+/* The GPU that is current for the calling thread (the one every "device pointer" argument refers to),
+ * and a way to choose it, for host languages without a HIP binding of their own: a program that shards
+ * streams over several GPUs calls the device-pointer entries from one thread or process per GPU, each
+ * after bd_set_device.  BD_ERR_NO_DEVICE for an index outside [0, bd_device_count).  No counterpart in
+ * the reference (it runs on one CPU thread, src/record.rs:87). */
+int bd_current_device(int *device);
+int bd_set_device(int device);
+
 /* Name and memory of GPU `device`: the analysis-side counterpart of the reference's device listing
  * helpers (record::audio_input_device_list / print_audio_input_device_configs / get_backends,
  * src/record.rs:168-198, which enumerate cpal audio devices; audio capture itself stays with the caller).

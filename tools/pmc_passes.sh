@@ -14,6 +14,9 @@ PASSES=(
  "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum"
  "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_BUSY_sum"
  "TCC_TAG_STALL_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_STALL_sum"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WR_UNCACHED_32B_sum"
+ "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_IO_CREDIT_STALL_sum TCC_EA0_WRREQ_GMI_CREDIT_STALL_sum TCC_WRITE_sum"
+ "TCP_TCC_WRITE_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCC_NC_WRITE_REQ_sum TCP_TCC_UC_WRITE_REQ_sum"
  "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE GRBM_TA_BUSY"
 )
 # PMC_ONLY="<counters>" runs that one pass instead
