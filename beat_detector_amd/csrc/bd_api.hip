@@ -114,6 +114,7 @@ static const bd_tuning *bd_tuning_read()
     t->spec_store = (int)num("BD_SPEC_STORE");
     t->split_no_rem = set("BD_SPLIT_NO_REM");
     t->split_stage = (int)num("BD_SPLIT_STAGE");
+    t->split_subruns = (int)num("BD_SPLIT_SUBRUNS");
     t->lpf_variant = (int)num("BD_LPF_VARIANT");
     const long long thr = num("BD_HOST_THREADS");
     t->host_threads = thr > 0 ? (unsigned)thr : 0u;

@@ -50,6 +50,7 @@ struct bd_tuning {
     int      spec_depth;             // BD_SPEC_DEPTH: register buffers of the half-block kernel (2, 3, 4; 0 = default)
     int      spec_store;             // BD_SPEC_STORE: result-store variant of the half-block kernel (0 = default)
     int      split_no_rem;           // BD_SPLIT_NO_REM: remainder as a masked piece of the main loop
+    int      split_subruns;          // BD_SPLIT_SUBRUNS: runs of 64 callbacks per wavefront of the split kernel (0 = automatic)
     int      split_stage;            // BD_SPLIT_STAGE: 1 = every length through the staged copy, 2 = rows straight from memory wherever possible
     int      lpf_variant;            // BD_LPF_VARIANT: chunk size / wavefronts per workgroup
     unsigned host_threads;           // BD_HOST_THREADS: packing threads of bd_analyze_batch_host (0 = default)

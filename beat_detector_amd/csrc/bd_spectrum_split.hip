@@ -63,6 +63,7 @@ struct bd_split_args {
     uint64_t       n_cb;            // callbacks per stream that this kernel evaluates: 0 .. n_cb - 1
     uint64_t       n_tasks;
     uint32_t       runs_per_stream, callback_len;
+    uint32_t       subruns;         // runs of BD_SPLIT_RUN callbacks that one wavefront walks, one after the other
     uint32_t       q, head_len, tail_len;
     uint32_t       min_amp, include_dc;
     float          divisor, threshold;
@@ -265,11 +266,10 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const uint64_t task = bd_block_index() * WAVES + wave;
     if (task >= a.n_tasks) return;
     const uint64_t s = task / a.runs_per_stream;
-    const int64_t j0 = (int64_t)(task - s * a.runs_per_stream) * BD_SPLIT_RUN;
-    const int64_t left = (int64_t)a.n_cb - j0;
-    const int n_win = left < BD_SPLIT_RUN ? (int)left : BD_SPLIT_RUN;
-    const int n_it = (n_win + ROWS - 1) / ROWS;
-    const int it_begin = j0 > 0 ? -1 : 0;   // the q callbacks before the run (q <= ROWS); none before the stream
+    // A wavefront walks `subruns` consecutive runs of BD_SPLIT_RUN callbacks.  Only the first of them reads the
+    // q callbacks before it again (one extra iteration); the others find those callbacks' sums where
+    // the run before them left them, moved to the front of the LDS slots.
+    const int64_t j_task = (int64_t)(task - s * a.runs_per_stream) * BD_SPLIT_RUN * (int64_t)a.subruns;
     const int16_t *sp = a.samples + s * a.stride;
     const int64_t L = a.callback_len;
     bd_split_slot *slots = lds_slots[wave];
@@ -331,11 +331,21 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     auto shift_of = [&](int64_t j) -> int {
         return SH ? (int)((((uintptr_t)sp + (uintptr_t)(j * L * 2)) & 15) >> 1) : 0;
     };
-    const int64_t ja = j0 + ROWS * (int64_t)(j0 > 0 ? -1 : 0) + g;      // this lane's row in the first iteration
-    const lane_set KA = make_set(shift_of(ja)), KB = make_set(shift_of(ja + ROWS));
+    // K0: this lane's rows in the even iterations (callbacks j + g, j + 2 ROWS + g, ... of a run that starts at
+    // callback j), K1: in the odd ones and in the iteration before the run (-1).  A run is 128 L bytes long, a
+    // multiple of 16: the sets serve every run of the task.
+    const lane_set K0 = make_set(shift_of(j_task + g)), K1 = make_set(shift_of(j_task + ROWS + g));
     const int o_last = GROUP * PL + 8 * l;   // (staged kernels: grid position of the lane's last piece)
-    const int off_last = KA.off_last;
+    const int off_last = K0.off_last;
 
+    for (int sub = 0; sub < (int)a.subruns; sub++) {
+    const int64_t j0 = j_task + (int64_t)sub * BD_SPLIT_RUN;
+    const int64_t left = (int64_t)a.n_cb - j0;
+    if (left <= 0) break;
+    const int n_win = left < BD_SPLIT_RUN ? (int)left : BD_SPLIT_RUN;
+    const int n_it = (n_win + ROWS - 1) / ROWS;
+    const bool warm = sub == 0 && j0 > 0;   // the q callbacks before the run (q <= ROWS) are read again; none before the stream
+    const int it_begin = warm ? -1 : 0;
     const int64_t j_last = j0 + n_win - 1;
     // The staged copy counts bytes from `run_ptr`, the 16-byte line that holds the first sample this
     // run reads (callback `cb0`): 32-bit arithmetic inside the loop, and every load address stays an
@@ -351,7 +361,6 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int first_rel = (int)(j0 - cb0), last_rel = (int)(j_last - cb0);   // the run's callbacks, counted from cb0
     uint4 A[NBUF];
     uint4 B[STAGED ? 1 : NBUF];
-    const int it_first = it_begin;
     const int64_t run_base = (int64_t)(s * a.stride) + j0 * L;   // the run's first sample, counted from a.samples
     const int run_lo = (int)(((((uintptr_t)a.samples & 15) >> 1) + (uint64_t)run_base) & 7);   // its place in its 16-byte line
     auto load = [&](uint4 (&d)[NBUF], int it) {
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             const int rel = jr * (int)L;                                        // samples from the run's first callback
             const int back = (run_lo + rel) & 7;                                // the row's shift, in samples
             const int16_t *cp = a.samples + run_base + (rel - back);
-            const int ol = (it - it_first) & 1 ? KB.off_last : KA.off_last;
+            const int ol = it & 1 ? K1.off_last : K0.off_last;
 #pragma unroll
             for (int p = 0; p < PIECES; p++)
                 d[p] = bd_load_stream16(cp + (p < PL ? GROUP * p + 8 * l : ol));
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             // SH: whole 16-byte units of the copy from the one that holds the row's first sample (the copy
             // starts on a 16-byte line of memory); otherwise five dwords from the one below the piece
             const char *sb = reinterpret_cast<const char *>(stage) + (row_off & (SH ? ~15u : ~3u));
-            const int ol = (it - it_first) & 1 ? KB.off_last : KA.off_last;
+            const int ol = it & 1 ? K1.off_last : K0.off_last;
 #pragma unroll
             for (int p = 0; p < NPC; p++) {
                 if (p == PIECES && l >= REM_UNITS) break;   // the remainder's units: the row's first lanes
@@ -554,17 +563,23 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        int it = it_begin;
+        if (warm) {   // the iteration before the run, on its own
+            load(A, -1);
+            put(A);
+            pick(P, -1);
+            sums(P, -1, K1);
+        }
+        int it = 0;
         load(A, it);
         put(A);
         if (it + 1 < n_it) load(A, it + 1);
         pick(P, it);
         for (;;) {
             advance(Q, it);
-            sums(P, it, KA);
+            sums(P, it, K0);
             if (++it >= n_it) break;
             advance(P, it);
-            sums(Q, it, KB);
+            sums(Q, it, K1);
             if (++it >= n_it) break;
         }
     } else {
@@ -572,23 +587,30 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             compute(d, it, K);
             if (REM && l < REM_UNITS) keep[ROWS * it + g + ROWS][1 + l] = d[NBUF - 1];
         };
-        int it = it_begin;
-        load(A, it);
+        if (warm) {   // the iteration before the run, on its own
+            load(B, -1);
+            load(A, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            run(B, -1, K1);
+        } else {
+            load(A, 0);
+        }
+        int it = 0;
         for (; it + 2 < n_it; it += 2) {
             load(B, it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            run(A, it, KA);
+            run(A, it, K0);
             load(A, it + 2);
             __builtin_amdgcn_sched_barrier(0);
-            run(B, it + 1, KB);
+            run(B, it + 1, K1);
         }
         if (it + 1 < n_it) {
             load(B, it + 1);
             __builtin_amdgcn_sched_barrier(0);
-            run(A, it, KA);
-            run(B, it + 1, KB);
+            run(A, it, K0);
+            run(B, it + 1, K1);
         } else {
-            run(A, it, KA);
+            run(A, it, K0);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -664,6 +686,19 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         bd_store_stream_u8(rf, (unsigned)i, flag ? 1 : 0);
         bd_store_stream_f32(rv, (unsigned)i * 4u, value);       // a zero-sized descriptor drops the store
     }
+    // the next run of this wavefront finds its ROWS predecessors at the front of the slots
+    if (sub + 1 < (int)a.subruns && n_win == BD_SPLIT_RUN) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ROWS) {
+            slots[lane] = slots[BD_SPLIT_RUN + lane];
+#pragma unroll
+            for (int u = 0; u < KEEP; u++) keep[lane][u] = keep[BD_SPLIT_RUN + lane][u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    }   // runs of this wavefront
 }
 
 // Callback lengths that run faster with rows loaded straight from memory than through the staged copy:
@@ -695,10 +730,6 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     bd_split_args a;
     a.samples = samples; a.values = values; a.flags = flags;
     a.stride = stride; a.out_stride = out_stride; a.n_cb = n_cb_eval;
-    const uint64_t runs = (n_cb_eval + BD_SPLIT_RUN - 1) / BD_SPLIT_RUN;
-    if (runs > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
-    a.runs_per_stream = (uint32_t)runs;
-    a.n_tasks = n_streams * runs;
     a.callback_len = callback_len;
     a.q = BD_RING_LEN / callback_len;
     a.tail_len = BD_RING_LEN - a.q * callback_len;
@@ -730,6 +761,20 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     const bool direct = sh && mode != 1 && (mode == 2 || bd_split_prefers_direct(callback_len));
     const bool staged = !direct;
     const bool rem = !narrow && rem_len + (sh ? 7 : 0) <= BD_SPLIT_REM_MAX && !bd_tuning_get().split_no_rem;
+    // A wavefront of the staged kernels walks several runs of BD_SPLIT_RUN callbacks in a row (the runs after the
+    // first need no warm-up iteration: 441 samples 5.53 -> 5.78 TB/s with four, 300 5.26 -> 5.65 and 100 3.4 -> 4.0
+    // with eight), fewer where the batch would otherwise leave CUs without work.  The kernels that load rows
+    // straight from memory keep one run per wavefront (529 samples: 6.05 TB/s with one, 5.75 - 5.85 with more).
+    const uint64_t runs64 = (n_cb_eval + BD_SPLIT_RUN - 1) / BD_SPLIT_RUN;
+    uint32_t subruns = staged ? (narrow ? 8 : 4) : 1;
+    const int knob = bd_tuning_get().split_subruns;
+    if (knob >= 1 && knob <= 64) subruns = (uint32_t)knob;
+    else while (subruns > 1 && n_streams * ((runs64 + subruns - 1) / subruns) < 16384) subruns >>= 1;
+    const uint64_t runs = (runs64 + subruns - 1) / subruns;
+    if (runs > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
+    a.subruns = subruns;
+    a.runs_per_stream = (uint32_t)runs;
+    a.n_tasks = n_streams * runs;
     const unsigned waves = (unsigned)bd_split_waves(staged, rem);
     dim3 grid;
     if (!bd_grid_dims((a.n_tasks + waves - 1) / waves, &grid)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }

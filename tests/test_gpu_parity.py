@@ -136,6 +136,32 @@ def test_spectrum_split_kernel_callback_lengths(bd, oracle, L):
     np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
 
 
+@pytest.mark.parametrize("subruns", [2, 3, 8])
+def test_spectrum_split_kernel_several_runs_per_wavefront(bd, oracle, knobs, subruns):
+    """A wavefront that walks several runs of 64 callbacks carries the sums of the last callbacks from run to
+    run instead of reading them again (small batches use one run per wavefront, so the switch forces it):
+    every flavour of the kernel, streams that end inside a run, on a run boundary and one callback after it,
+    rows at odd addresses."""
+    import torch
+    knobs.set("BD_SPLIT_SUBRUNS", subruns)
+    for L in (100, 127, 150, 300, 383, 400, 441, 500, 513, 529, 540, 639, 700):
+        for n_cb, streams in ((64 * subruns * 2 + 37, 2), (64 * subruns, 1), (64 * subruns + 1, 2), (64 * 5 + 63, 1)):
+            n = n_cb * L + L // 3 + L                       # + L: the last callback goes to the generic kernel
+            x = _synth(bd, streams, n, first=11 + L)
+            _compare(bd, oracle, "Spectrum", SR, x, L)
+            assert bd.last_kernel_name() == "bd_spectrum_split_kernel"
+        n = 64 * 3 * L + 5 * L + 3
+        x = _synth(bd, 3, n, first=5)
+        flat = torch.zeros(3 + 3 * (n + 1), dtype=torch.int16, device="cuda")
+        view = flat[3:].view(3, n + 1)
+        view[:, :n] = torch.from_numpy(x).cuda()
+        res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, view, L, n_samples=n)
+        ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_SPECTRUM, SR, x, L)
+        assert util.values_close(res.values.cpu().numpy(), ref_v, 32768, 3).all(), L
+        adjacent = util.threshold_adjacent(ref_v, 2.1e6)
+        assert ((res.flags.cpu().numpy() == ref_c) | adjacent).all(), L
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
     """Random callback lengths in the split kernel's range, stream counts and lengths (runs of 64
@@ -163,7 +189,8 @@ def test_spectrum_split_kernel_random_shapes(bd, oracle, seed):
         view = flat[shift:].view(streams, stride)
         view[:, :n] = torch.from_numpy(x).cuda()
         bp, op = bd.Params.default(**kw), oracle.default_params(**kw)
-        res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, view, L, n_samples=n, params=bp)
+        with bd.tuning(split_subruns=int(rng.integers(1, 6)), split_stage=int(rng.integers(0, 3))):
+            res = bd.analyze_batch(bd.StrategyKind.Spectrum, SR, view, L, n_samples=n, params=bp)
         assert bd.last_kernel_name() == "bd_spectrum_split_kernel"
         ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_SPECTRUM, SR, x, L, op)
         nb, _, _ = oracle.bin_range(SR, op)
