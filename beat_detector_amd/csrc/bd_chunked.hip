@@ -145,6 +145,10 @@ static int bd_chunked_pass(bd_chunked *ex, bd_chunk_source_fn source, void *user
         BD_HIP(hipEventRecord(ex->filled[slot], ex->fill));
         return BD_OK;
     };
+    // The intermediate buffer (decisions / flux) is shared by every pass: a pass on another stream than the
+    // one before it waits until that pass's last analyses, which may still use the buffer, have finished.
+    for (int slot = 0; slot < 2; slot++)
+        if (ex->consumed_valid[slot]) BD_HIP(hipStreamWaitEvent(run, ex->consumed[slot], 0));
     if (n_chunks) { const int s = fill(0); if (s != BD_OK) return s; }
     for (uint64_t c = 0; c < n_chunks; c++) {
         const int slot = (int)(c & 1);

@@ -633,18 +633,26 @@ def run_live(ctx, ticks=400, streams=256, L=1024):
     # author reports for Linux, spectrum.rs:40-42)
     rng = np.random.default_rng(1)
     var_len = rng.integers(500, 541, ticks)
+    # and with every stream drawing its own 500-540 samples per tick (each stream is a device of its own in
+    # the reference, record.rs:93-95: concurrent streams do not deliver equal lengths): bd_live_submit_ragged
+    ragged_len = rng.integers(500, 541, (ticks, streams)).astype(np.uint32)
+    ragged_blk = [np.ascontiguousarray(x[:, 100 * i:100 * i + 540]) for i in range(8)]
     for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
-        for label, lengths in ((kind.name, None), (kind.name + "_500_540", var_len)):
+        for label, lengths in ((kind.name, None), (kind.name + "_500_540", var_len), (kind.name + "_ragged_500_540", "ragged")):
+            ragged = isinstance(lengths, str)
             live = bd.Live(kind, SR, streams, max_callback_len=L, depth=4)
-            blocks = wins if lengths is None else [np.ascontiguousarray(x[:, 100 * (t % 8):100 * (t % 8) + int(n)])
-                                                   for t, n in enumerate(lengths)]
+            if ragged:
+                blocks = ragged_blk
+            else:
+                blocks = wins if lengths is None else [np.ascontiguousarray(x[:, 100 * (t % 8):100 * (t % 8) + int(n)])
+                                                       for t, n in enumerate(lengths)]
             lat = []
             gc.collect()
             gc.disable()   # a collection of the interpreter's heap inside a tick is not the path's latency
             for t in range(ticks):                     # every tick counts: the first ones included
                 blk = blocks[t % len(blocks)]
                 t0 = time.perf_counter()
-                tick = live.submit(blk)
+                tick = live.submit_ragged(blk, ragged_len[t]) if ragged else live.submit(blk)
                 live.poll(tick)
                 lat.append((time.perf_counter() - t0) * 1e6)
             gc.enable()

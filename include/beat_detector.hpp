@@ -101,6 +101,53 @@ inline uint32_t min_duration_between_beats_ms(StrategyKind kind)
 /// StrategyKind::values, src/lib.rs:182-184
 inline std::vector<StrategyKind> values() { return {StrategyKind::LPF, StrategyKind::Spectrum}; }
 
+/// Many concurrent input streams advanced together, one callback per stream and tick (bd_live_*): the
+/// multi-stream form of the loop in src/record.rs:87-146.  One thread at a time per engine.
+class Live {
+public:
+    Live(StrategyKind kind, uint32_t sampling_rate, uint32_t n_streams, uint32_t max_callback_len,
+         const bd_params *params = nullptr, int device = -1) : n_streams_(n_streams)
+    {
+        const int rc = bd_live_create(static_cast<int>(kind), sampling_rate, params, n_streams, max_callback_len, 0, device, &raw_);
+        if (rc != BD_OK) throw std::runtime_error("bd_live_create: " + detail::last_error());
+    }
+    ~Live() { bd_live_destroy(raw_); }
+    Live(const Live &) = delete;
+    Live &operator=(const Live &) = delete;
+
+    /// One tick of i16 samples [n_streams][n]: the beat of every stream.
+    std::vector<std::optional<BeatInfo>> tick(const int16_t *samples, uint32_t n)
+    {
+        uint64_t id = 0;
+        if (bd_live_submit(raw_, samples, n, BD_FMT_I16, &id) != BD_OK) throw std::runtime_error("bd_live_submit: " + detail::last_error());
+        return collect(id);
+    }
+    /// One tick in which stream m brings lengths[m] samples, the first ones of row m of
+    /// samples [n_streams][row_pitch]; 0 skips the stream (every stream is a device of its own in the
+    /// reference and gets its own data.len(): src/record.rs:93-95, 107-109, 121-123).
+    std::vector<std::optional<BeatInfo>> tick_ragged(const int16_t *samples, const uint32_t *lengths, uint32_t row_pitch)
+    {
+        uint64_t id = 0;
+        if (bd_live_submit_ragged(raw_, samples, lengths, row_pitch, BD_FMT_I16, &id) != BD_OK)
+            throw std::runtime_error("bd_live_submit_ragged: " + detail::last_error());
+        return collect(id);
+    }
+
+private:
+    std::vector<std::optional<BeatInfo>> collect(uint64_t id)
+    {
+        std::vector<uint8_t> beats(n_streams_);
+        std::vector<uint32_t> ms(n_streams_);
+        if (bd_live_poll(raw_, id, 1, beats.data(), ms.data(), nullptr) < 0) throw std::runtime_error("bd_live_poll: " + detail::last_error());
+        std::vector<std::optional<BeatInfo>> out(n_streams_);
+        for (uint32_t m = 0; m < n_streams_; m++)
+            if (beats[m]) out[m] = BeatInfo(ms[m]);
+        return out;
+    }
+    bd_live *raw_ = nullptr;
+    uint32_t n_streams_;
+};
+
 /// Result<T, String>
 template <class T>
 struct Result {

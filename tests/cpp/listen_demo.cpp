@@ -53,5 +53,22 @@ int main(int argc, char **argv)
     for (size_t p = 0; p + 1024 <= audio.size(); p += 1024)
         if (det->is_beat(audio.data() + p, 1024)) beats++;
     std::printf("detector beats %zu\n", beats);
+
+    // two streams through the live engine, each with its own callback lengths in every tick: stream 0 is the
+    // same audio in callbacks of 1024, stream 1 the same audio in callbacks of 512 (two ticks per callback of
+    // stream 0, which skips every other tick)
+    Live live(strategy, sr, 2, 1024);
+    std::vector<int16_t> rows(2 * 1024);
+    size_t beats0 = 0, beats1 = 0, p0 = 0, p1 = 0;
+    for (size_t t = 0; p1 + 512 <= audio.size(); t++) {
+        uint32_t len[2] = {0, 512};
+        if (t % 2 == 0 && p0 + 1024 <= audio.size()) { std::memcpy(rows.data(), audio.data() + p0, 1024 * sizeof(int16_t)); len[0] = 1024; p0 += 1024; }
+        std::memcpy(rows.data() + 1024, audio.data() + p1, 512 * sizeof(int16_t));
+        p1 += 512;
+        const auto r = live.tick_ragged(rows.data(), len, 1024);
+        beats0 += r[0].has_value();
+        beats1 += r[1].has_value();
+    }
+    std::printf("live ragged beats %zu %zu\n", beats0, beats1);
     return 0;
 }

@@ -43,3 +43,6 @@ def test_cpp_demo_reports_the_oracle_beats(bd, oracle, kind):
     want = [ms for _, ms in beats]
     assert got == want and len(want) > 0
     assert f"detector beats {len(want)}" in lines
+    # the live engine with a callback length per stream and tick: stream 0 in callbacks of 1024, stream 1 in 512
+    _, _, beats512 = oracle.run_stream(kind, 44100, x, 512, full=False)
+    assert f"live ragged beats {len(want)} {len(beats512)}" in lines

@@ -51,6 +51,32 @@ def test_chunked_strategies_equal_one_launch(bd, chunk):
         ex.close()
 
 
+def test_chunked_passes_on_alternating_streams(bd):
+    """Consecutive passes of one executor on two different HIP streams, nothing synchronised in between: the
+    intermediate buffer they share must not be rewritten by one pass while the other still uses it."""
+    import torch
+    n_streams, n, seed = 48, SR * 8 + 77, 31
+    whole = torch.zeros((n_streams, (n + 63) & ~63), dtype=torch.int16, device="cuda:0")
+    bd.synth_fill(whole, n_samples=n, seed=seed)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ex = bd.ChunkedExecutor(5, n)
+    try:
+        jobs = []
+        for i, (kind, L) in enumerate(((bd.StrategyKind.Spectrum, 512), (bd.StrategyKind.LPF, 1024),
+                                       (bd.StrategyKind.Spectrum, 529), (bd.StrategyKind.LPF, 441)) * 2):
+            mb = bd.batch_max_beats(kind, SR, n, L)
+            out = _outputs(torch, n_streams, mb)
+            ex.analyze(kind, SR, L, n_streams, *out, seed=seed, stream=streams[i % 2])
+            jobs.append((kind, L, mb, out))
+        torch.cuda.synchronize()
+        for kind, L, mb, (count, idx, ms) in jobs:
+            want = bd.analyze_batch(kind, SR, whole, L, n_samples=n, max_beats=mb)
+            got, gc = _lists(count, idx, ms)
+            assert got == [want.beats(s) for s in range(n_streams)], (kind, L)
+    finally:
+        ex.close()
+
+
 def test_chunked_onset_equals_one_launch_and_caller_sources(bd):
     import torch
     n_streams, n, seed = 21, SR * 6, 22

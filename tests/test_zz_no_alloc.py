@@ -58,8 +58,10 @@ def test_noalloc_matches_analyze_batch_on_consecutive_calls(bd):
     small = torch.zeros((17, (n2 + 7) & ~7), dtype=torch.int16, device=dev)
     bd.synth_fill(small, n_samples=n2, seed=12, first_stream=1000)
     torch.cuda.synchronize()
+    # (96: granules of 32 samples, 900: the window kernel, 1536: granules of 64, 7: the generic kernel)
     for kind, L in ((bd.StrategyKind.Spectrum, 512), (bd.StrategyKind.LPF, 1024), (bd.StrategyKind.Spectrum, 441),
-                    (bd.StrategyKind.Spectrum, 529)):
+                    (bd.StrategyKind.Spectrum, 529), (bd.StrategyKind.Spectrum, 96), (bd.StrategyKind.Spectrum, 900),
+                    (bd.StrategyKind.Spectrum, 1536), (bd.StrategyKind.LPF, 441)):
         mb1 = bd.batch_max_beats(kind, SR, n1, L)
         mb2 = bd.batch_max_beats(kind, SR, n2, L)
         want1 = _expect(bd, torch, kind, big, n1, L, mb1)
@@ -70,6 +72,41 @@ def test_noalloc_matches_analyze_batch_on_consecutive_calls(bd):
         _same(got2, want2, mb2)
         # and once more the large one after the small one
         _same(_raw_call(bd, torch, kind, big, n1, L, mb1), want1, mb1)
+
+
+def test_noalloc_just_under_capacity_uses_dense_rows(bd):
+    """A batch whose decision rows fit the fixed array only when packed densely (rows padded to 128-byte lines
+    would not): 18,000 streams x 5,512 callbacks of 16 samples = 99.2 M of the 100.7 M callbacks the array holds.
+    The unaligned dense rows go through a strategy kernel and the refractory pass; streams from both ends and the
+    middle of the batch must equal bd_analyze_batch on those streams alone."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_streams, L = 18000, 16
+    n = SR * 2                             # 5,512 callbacks: two seconds, a few clicks in every stream
+    n_cb = n // L
+    cap = bd.NOALLOC_MAX_CALLBACKS
+    assert n_streams * ((n_cb + 127) & ~127) > cap >= n_streams * n_cb
+    x = torch.zeros((n_streams, (n + 7) & ~7), dtype=torch.int16, device=dev)
+    bd.synth_fill(x, n_samples=n, seed=14)
+    torch.cuda.synchronize()
+    for kind in (bd.StrategyKind.Spectrum, bd.StrategyKind.LPF):
+        mb = bd.batch_max_beats(kind, SR, n, L)
+        gc, gi, gm = _raw_call(bd, torch, kind, x, n, L, mb)
+        # (the low-pass strategy finds no beat in windows of 16 samples, here as in the reference: its rows of
+        # zeros are compared all the same)
+        assert gc.sum() > 100000 or kind == bd.StrategyKind.LPF
+        for lo in (0, n_streams // 2 - 100, n_streams - 200):
+            wc, wi, wm = _expect(bd, torch, kind, x[lo:lo + 200], n, L, mb)
+            assert (gc[lo:lo + 200] == wc).all(), (kind, lo)
+            for s in range(200):
+                k = min(int(wc[s]), mb)
+                assert (gi[lo + s, :k] == wi[s, :k]).all() and (gm[lo + s, :k] == wm[s, :k]).all(), (kind, lo, s)
+        # a small call right after it (the array is full of the large call's decisions)
+        small = x[:9]
+        if gc[:9].sum():
+            _same(_raw_call(bd, torch, kind, small, n, L, mb), _expect(bd, torch, kind, small, n, L, mb), mb)
+    del x
+    torch.cuda.empty_cache()
 
 
 def test_noalloc_on_a_side_stream_and_truncated_lists(bd):
