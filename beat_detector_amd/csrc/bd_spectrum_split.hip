@@ -243,7 +243,8 @@ __device__ __forceinline__ void bd_split_reduce16(float a, float b, float c, flo
 // ring spans up to seven whole callbacks; 4 (groups of 32 samples, sixteen callbacks per iteration) for
 // 65 .. 127 samples: up to fifteen whole callbacks.
 // SH: rows are read on the grid of 16-byte lines (see the comment at `lane_set` below).
-template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16, bool SH = !STAGED>
+// MULTI: a wavefront walks a.subruns runs (else one: the loop over runs costs registers even when it runs once).
+template <int NK, int PSTAR, int PL, bool STAGED, bool REM, int LPC = 16, bool SH = !STAGED, bool MULTI = STAGED>
 __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_split_kernel(bd_split_args a)
 {
     constexpr int WAVES = bd_split_waves(STAGED, REM);
@@ -260,8 +261,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     __shared__ __attribute__((aligned(16))) uint4 lds_keep[WAVES][BD_SPLIT_RUN + ROWS][KEEP];
     __shared__ __attribute__((aligned(16))) uint4 lds_stage[STAGED ? WAVES : 1][STAGED ? 64 * LOADS + 2 : 1];
 
-    const int lane = threadIdx.x & 63;
-    const int g = lane / LPC, l = lane % LPC;
+    const int lane_id = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t task = bd_block_index() * WAVES + wave;
     if (task >= a.n_tasks) return;
@@ -275,6 +275,14 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     bd_split_slot *slots = lds_slots[wave];
     uint4 (*keep)[KEEP] = lds_keep[wave];
     const int q_cb = (int)a.q;
+
+    // MULTI: the wavefront walks several runs.  Everything a lane derives from its number is then derived anew
+    // in every run (the lane number is made opaque at the top of the loop): kept across the loop, those values
+    // stay in registers through every run's finish pass and cost the kernel a wavefront per SIMD.
+    for (int sub = 0; sub < (MULTI ? (int)a.subruns : 1); sub++) {
+    int lane = lane_id;
+    if (MULTI) asm volatile("" : "+v"(lane));
+    const int g = lane / LPC, l = lane % LPC;
 
     // ---- what a lane's place inside its callback fixes, once ----
     // SH: a row is read from the 16-byte line that holds its first sample -- of memory (the kernels that do
@@ -338,7 +346,6 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     const int o_last = GROUP * PL + 8 * l;   // (staged kernels: grid position of the lane's last piece)
     const int off_last = K0.off_last;
 
-    for (int sub = 0; sub < (int)a.subruns; sub++) {
     const int64_t j0 = j_task + (int64_t)sub * BD_SPLIT_RUN;
     const int64_t left = (int64_t)a.n_cb - j0;
     if (left <= 0) break;
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
         bd_store_stream_f32(rv, (unsigned)i * 4u, value);       // a zero-sized descriptor drops the store
     }
     // the next run of this wavefront finds its ROWS predecessors at the front of the slots
-    if (sub + 1 < (int)a.subruns && n_win == BD_SPLIT_RUN) {
+    if (MULTI && sub + 1 < (int)a.subruns && n_win == BD_SPLIT_RUN) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane < ROWS) {
@@ -768,7 +775,8 @@ int bd_launch_spectrum_split(const bd_plan &plan, const int16_t *samples, uint64
     const uint64_t runs64 = (n_cb_eval + BD_SPLIT_RUN - 1) / BD_SPLIT_RUN;
     uint32_t subruns = staged ? (narrow ? 8 : 4) : 1;
     const int knob = bd_tuning_get().split_subruns;
-    if (knob >= 1 && knob <= 64) subruns = (uint32_t)knob;
+    if (!staged) subruns = 1;                      // (those kernels are built for one run per wavefront)
+    else if (knob >= 1 && knob <= 64) subruns = (uint32_t)knob;
     else while (subruns > 1 && n_streams * ((runs64 + subruns - 1) / subruns) < 16384) subruns >>= 1;
     const uint64_t runs = (runs64 + subruns - 1) / subruns;
     if (runs > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
