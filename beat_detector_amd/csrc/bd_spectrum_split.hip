@@ -382,15 +382,22 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
             end = end < limit_rel ? end : limit_rel;
             const unsigned n_units = (end - base + 15) >> 4;
             const unsigned whole = (limit_rel - base) >> 4;         // units that end at or before the limit
-            const unsigned last_off = 16u * ((n_units < whole ? n_units : whole) - 1);
-            const char *bp = run_ptr + base;
-            // Units past the last one repeat it (nobody reads their copy): loads under a lane predicate
-            // would sit in branches, and the wait for this buffer would then have to be a wait for every
-            // load in flight, the next iteration's included.
+            // Through a buffer descriptor over exactly these units: the loads past the last one are dropped by the
+            // range check (no memory access, zeros that nobody reads), every load is unconditional -- a load
+            // under a lane predicate would turn the wait for this buffer into a wait for every load in flight,
+            // the next iteration's included -- and no per-lane address arithmetic is left: the descriptor moves
+            // (scalar registers: everything it is made of is the same in all lanes), the lane's offset 16 * lane
+            // never changes.
+            const uint64_t ubase = (uint64_t)(uintptr_t)run_ptr + base;
+            const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)ubase);
+            const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ubase >> 32));
+            const uint32_t n_rec = __builtin_amdgcn_readfirstlane(16u * (n_units < whole ? n_units : whole));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<void *>((uintptr_t)(((uint64_t)b_hi << 32) | b_lo)), 0, (int)n_rec, 0x00020000);
 #pragma unroll
             for (int i = 0; i < LOADS; i++) {
-                const unsigned off = 16u * (unsigned)lane + 1024u * i;
-                d[i] = bd_load_stream16(bp + (off < last_off ? off : last_off));
+                const bd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 16u * (unsigned)lane, 1024 * i, 2 /* nt */);
+                d[i] = make_uint4(v.x, v.y, v.z, v.w);
             }
         } else {
             // the row, counted from the run's first callback (32-bit arithmetic per lane)
