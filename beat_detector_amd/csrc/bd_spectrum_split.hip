@@ -715,15 +715,17 @@ __global__ __launch_bounds__(64 * bd_split_waves(STAGED, REM)) void bd_spectrum_
     }   // runs of this wavefront
 }
 
-// Callback lengths that run faster with rows loaded straight from memory than through the staged copy:
-// those whose remainder past the last whole group of 128 is short enough to be parked (at most 17 samples,
-// so the direct kernel has no masked piece).  Measured at 16,384 streams x 60 s, direct / staged: 385 5.43 /
-// 5.21 TB/s, 400 5.58 / 5.32, 517 5.78 / 5.66, 529 5.96 / 5.69, 641 5.97 / 5.92; with a masked piece the
-// staged copy wins: 420 5.21 / 5.43, 441 5.38 / 5.52, 450 5.39 / 5.61, 500 5.86 / 6.05, 532 5.65 / 5.71,
-// 600 5.91 / 6.16, 700 5.86 / 6.18, 730 6.01 / 6.35.
+// Callback lengths that run faster with rows loaded straight from memory than through the staged copy.
+// Since the staged kernels walk several runs per wavefront and load through a descriptor, they are level
+// with the direct kernels or ahead of them almost everywhere; the direct kernels keep 525 .. 529 samples
+// (remainder of 13 .. 17 past four groups of 128, parked).  Measured at 16,384 streams x 60 s, whole call,
+// staged / direct in TB/s: 385 5.44 / 5.38, 398 5.40 / 5.45, 401 5.46 / 5.44, 441 5.81 / 5.31, 500 6.10 / 5.79,
+// 514 5.88 / 5.88, 517 5.98 / 5.71, 520 6.07 / 5.75, 522 5.85 / 5.70, 524 5.95 / 5.92, 525 5.78 / 5.90,
+// 527 5.79 / 5.91, 528 5.94 / 6.02, 529 5.78 / 5.93, 532 5.97 / 5.62, 600 6.25 / 5.86, 641 6.17 / 5.89,
+// 654 6.03 / 5.95, 657 6.14 / 6.04, 700 6.34 / 5.81, 767 6.38 / 6.37.
 static bool bd_split_prefers_direct(uint32_t callback_len)
 {
-    return callback_len % 128 <= 17;
+    return callback_len >= 525 && callback_len <= 529;
 }
 
 bool bd_spectrum_split_applies(const bd_plan &plan, uint32_t callback_len)
