@@ -9,7 +9,8 @@
 // HBM read per sample.  Nothing here is a dense contraction; the kernel is
 // bound by HBM bandwidth.
 //
-// Fast kernel (callback length 512 or 1024, 16-byte aligned rows)
+// Fast kernel (callback length 512, 1024, or a longer multiple of 512 up to 8192 -- then only the
+// callback's last two half-blocks form the ring; 16-byte aligned rows)
 //   Samples are consumed in half-blocks of 512.  With
 //       P_k(h) = sum_{n<512} x[512 h + n] W^{k n},   W = exp(-2 pi i / 1024)
 //   the DFT of the ring [half-block h-1 | half-block h] is
@@ -52,6 +53,7 @@ struct bd_spec_args {
     float          divisor;
     float          threshold;
     uint32_t       store_mode;      // result-store variant; only builds with BD_STORE_EXPERIMENT look at it
+    uint32_t       hb_per_cb;       // half-blocks per callback (callbacks of 1536 .. 8192 samples: 3 .. 16)
 };
 
 static __device__ const float bd_cos1024[1024] = {
@@ -85,7 +87,8 @@ __device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], __amdgpu_buffer_rsrc_t
 // apart put the 16 lanes that such a read serves together on 64 different banks (one 32-byte record
 // per half-block put two of them on every bank).  Half-block h of the run sits at entry
 // bd_spec_entry(h): as it comes for 512-sample callbacks (lane i reads h = i, i + 1), even and odd
-// half-blocks in two halves of the plane for 1024-sample callbacks (lane i reads h = 2 i, 2 i + 1).
+// half-blocks in two halves of the plane for 1024-sample callbacks (lane i reads h = 2 i, 2 i + 1); callbacks
+// of m > 2 half-blocks keep the plain order (lane i reads h = m i .. m i + m - 1, once per run).
 struct __attribute__((aligned(16))) bd_spec_sums { float re1, im1, re2, im2; };
 struct __attribute__((aligned(16))) bd_spec_misc { int dc, ny; float amax, pad; };
 #define BD_SPEC_SLOTS (BD_SPEC_MAX_RUN + 4)
@@ -95,7 +98,7 @@ struct bd_spec_slots {
 };
 template <int MODE> __device__ __forceinline__ int bd_spec_entry(int h)
 {
-    return MODE == 0 ? h : ((h & 1) * (BD_SPEC_SLOTS / 2) + (h >> 1));
+    return MODE != 1 ? h : ((h & 1) * (BD_SPEC_SLOTS / 2) + (h >> 1));
 }
 
 // One iteration: four half-blocks (one per row of 16 lanes) held in `d`; the row's sums go to
@@ -161,13 +164,15 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
     }
 }
 
-// Callback i of the run from the sums of its two half-blocks: X_k = P_k(prev) + (-1)^k P_k(cur).
+// Callback i of the run from the sums of the two half-blocks its ring consists of: X_k = P_k(prev) +
+// (-1)^k P_k(cur).  A callback of m > 2 half-blocks ends on them; the ones before only feed the gate.
 template <int MODE, int NK, bool NYQ>
 __device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_spec_slots *slots, unsigned i,
                                                float *value_out, uint8_t *flag_out)
 {
-    const int ep = bd_spec_entry<MODE>(MODE == 0 ? (int)i : 2 * (int)i);
-    const int ec = bd_spec_entry<MODE>(MODE == 0 ? (int)i + 1 : 2 * (int)i + 1);
+    const int m = MODE == 2 ? (int)a.hb_per_cb : 2;
+    const int ep = bd_spec_entry<MODE>(MODE == 0 ? (int)i : m * (int)i + m - 2);
+    const int ec = bd_spec_entry<MODE>(MODE == 0 ? (int)i + 1 : m * (int)i + m - 1);
     const bd_spec_sums p = slots->sums[ep], c = slots->sums[ec];
     const bd_spec_misc pm = slots->misc[ep], cm = slots->misc[ec];
     const float x_dc = (float)(pm.dc + cm.dc);
@@ -187,14 +192,18 @@ __device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_s
     }
     const float value = (a.divisor == 0.f) ? best : best / a.divisor;
     // the amplitude gate looks at the callback's own samples (spectrum.rs:77): one half-block
-    // for 512-sample callbacks, both for 1024
-    const float wmax = fminf(MODE == 0 ? cm.amax : fmaxf(cm.amax, pm.amax), 32767.f);
+    // for 512-sample callbacks, both for 1024, all m of a longer callback
+    float amax = MODE == 0 ? cm.amax : fmaxf(cm.amax, pm.amax);
+    if (MODE == 2)
+        for (int h = 0; h < m - 2; h++) amax = fmaxf(amax, slots->misc[m * (int)i + h].amax);
+    const float wmax = fminf(amax, 32767.f);
     const bool gate = wmax >= (float)a.min_amp;
     *value_out = value;
     *flag_out = (gate && (value > a.threshold)) ? 1 : 0;
 }
 
-// MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024.
+// MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024; MODE 2: 512 m for m = 3 .. 16
+// (runs are whole callbacks: a.run_hbs is a multiple of m and of 4).
 // NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
 // DEPTH: register buffers of one iteration (4 KB per wavefront) each; loads run DEPTH - 1 iterations ahead.
 template <int MODE, int NK, bool NYQ, int DEPTH>
@@ -289,9 +298,9 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    const uint64_t cb0 = (uint64_t)(hb0 >> MODE);
+    const uint64_t cb0 = MODE == 2 ? (uint64_t)hb0 / a.hb_per_cb : (uint64_t)(hb0 >> MODE);
     const uint64_t cb_left = a.n_cb - cb0;
-    const unsigned n_res_run = (unsigned)(n_it * (MODE == 0 ? 4 : 2));
+    const unsigned n_res_run = MODE == 2 ? (unsigned)(n_it * 4) / a.hb_per_cb : (unsigned)(n_it * (MODE == 0 ? 4 : 2));
     const unsigned n_res = cb_left < n_res_run ? (unsigned)cb_left : n_res_run; // buffer stores past it are dropped
     const uint64_t o0 = s * a.out_stride + cb0;
     __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, n_res);
@@ -659,7 +668,10 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     const uint64_t n_cb = n_samples / callback_len;
     if (n_cb == 0 || n_streams == 0) return BD_OK;
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0);
-    const bool fast_len = callback_len == 512 || callback_len == 1024;
+    // 512 and 1024 samples, and the longer multiples of 512 up to 8192 (2048, 4096, ...: the ring is the
+    // callback's last two half-blocks)
+    const uint32_t hb_per_cb = callback_len / BD_HALF_BLOCK;
+    const bool fast_len = callback_len % BD_HALF_BLOCK == 0 && hb_per_cb >= 1 && hb_per_cb <= 16;
     const bool fast_bins = plan.last_bin <= 2;
     const bd_tuning &tune = bd_tuning_get();   // experiment switches, read from the environment once
     // spec_force_granule routes 512 / 1024 to the granule kernel as well (A/B experiments)
@@ -674,10 +686,14 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         // start; short streams still need enough wavefronts to fill 256 CUs.
         // (Measured on 16,384 streams x 60 s with two workgroups per CU: runs of 64 half-blocks 12.4 ms,
         // of 128 12.65 ms, of 32 12.9 ms.)
-        uint32_t run = 64;
-        while (run > 8 && n_streams * ((n_hb + run - 1) / run) < 32768) run >>= 1;
+        // (callbacks of m > 2 half-blocks: runs are multiples of lcm(4, m) half-blocks, 56 .. 64 at most)
+        uint32_t unit = 8;
+        if (hb_per_cb > 2) for (unit = hb_per_cb; unit % 4; unit += hb_per_cb) {}
+        uint32_t run = unit * (64 / unit);
+        while (run > unit && n_streams * ((n_hb + run - 1) / run) < 32768) run = unit * ((run / unit) / 2);
         const int run_override = tune.spec_run;
-        if (run_override >= 8 && run_override % 8 == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
+        if (run_override >= 8 && run_override % (int)unit == 0 && run_override <= BD_SPEC_MAX_RUN) run = (uint32_t)run_override;
+        a.hb_per_cb = hb_per_cb;
         a.run_hbs = run;
         a.runs_per_stream = (uint32_t)((n_hb + run - 1) / run);
         a.n_tasks = n_streams * a.runs_per_stream;
@@ -701,15 +717,20 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
             if (nk == 0) launch_fast<0, 0>(nyq, depth, a, grid, lds_pad, st);
             else if (nk == 1) launch_fast<0, 1>(nyq, depth, a, grid, lds_pad, st);
             else launch_fast<0, 2>(nyq, depth, a, grid, lds_pad, st);
-        } else {
+        } else if (callback_len == 1024) {
             if (nk == 0) launch_fast<1, 0>(nyq, depth, a, grid, lds_pad, st);
             else if (nk == 1) launch_fast<1, 1>(nyq, depth, a, grid, lds_pad, st);
             else launch_fast<1, 2>(nyq, depth, a, grid, lds_pad, st);
+        } else {
+            if (nk == 0) launch_fast<2, 0>(nyq, depth, a, grid, lds_pad, st);
+            else if (nk == 1) launch_fast<2, 1>(nyq, depth, a, grid, lds_pad, st);
+            else launch_fast<2, 2>(nyq, depth, a, grid, lds_pad, st);
         }
         bd_set_last_kernel("bd_spectrum_band_kernel");
         return bd_check_hip(hipGetLastError(), "launch bd_spectrum_band_kernel");
     }
-    // other multiples of 64 up to 4096, of 32 up to 512, of 16 up to 256: the granule kernel
+    // other multiples of 64 up to 4096 (those of 512 as well when the rows are not 16-byte aligned or the band
+    // holds more than three bins), of 32 up to 512, of 16 up to 256: the granule kernel
     // (BD_SPEC_NO_GRANULE=1 forces the generic one, BD_SPEC_NO_SMALL_GRANULE=1 the window kernel
     // for the lengths that need granules below 64 samples)
     // (also 512 / 1024 when the rows are not 16-byte aligned: it reads such rows with unaligned loads)

@@ -75,6 +75,37 @@ def test_spectrum_fast_path(bd, oracle, L):
     assert (ref_c == 0).sum() > 0
 
 
+@pytest.mark.parametrize("L", [1536, 2048, 2560, 3072, 3584, 4096, 4608, 5120, 5632, 6144, 6656, 7168, 7680, 8192])
+def test_spectrum_fast_path_long_callbacks(bd, oracle, knobs, L):
+    """Callbacks of 3 .. 16 half-blocks: the ring is the callback's last two half-blocks, the gate looks at all
+    of them.  Streams of one callback, of a few, of several runs with a partial last one; rows whose length is
+    no multiple of the callback; the unpinned choices; a batch that shortens the runs; other run lengths."""
+    for n, streams in ((L, 2), (3 * L + 5, 3), (L * 67 + 1001, 2), (L * 3 - 1, 1), (512 * 131, 2)):
+        x = _synth(bd, streams, n, first=7)
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+        if n >= L:
+            assert bd.last_kernel_name() == "bd_spectrum_band_kernel"
+    x = _synth(bd, 3, L * 40 + 9, first=21)
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
+               dict(spectrum_max_hz=50.0), dict(spectrum_max_hz=10.0)):
+        _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+    m = L // 512
+    unit = next(u for u in range(m, 200, m) if u % 4 == 0)
+    for run in (unit, 2 * unit):
+        if run <= 128:
+            knobs.set("BD_SPEC_RUN", str(run))
+            _compare(bd, oracle, "Spectrum", SR, x, L)
+    knobs.unset("BD_SPEC_RUN")
+    # a loud sample in each of the callback's half-blocks in turn opens the gate (quiet stream otherwise)
+    quiet = (_synth(bd, 1, L * 4, first=3) // 64).astype(np.int16)
+    kw = dict(spectrum_threshold=10.0, min_beat_gap_ms=0)    # every callback whose gate is open is a beat
+    for h in range(m):
+        y = quiet.copy()
+        y[0, 2 * L + 512 * h + 100] = 20000
+        res, _, ref_c, _ = _compare(bd, oracle, "Spectrum", SR, y, L, bd.Params.default(**kw), oracle.default_params(**kw))
+        assert ref_c[0].tolist() == [0, 0, 1, 0]
+
+
 def test_spectrum_ragged_lengths(bd, oracle):
     # lengths that are not multiples of the callback, of a half-block run, or of 8
     for n in (511, 512, 1023, 1024, 1537, 4096 + 3, 512 * 129 + 5, 1024 * 67 + 1001):
@@ -83,7 +114,7 @@ def test_spectrum_ragged_lengths(bd, oracle):
             _compare(bd, oracle, "Spectrum", SR, x, L)
 
 
-@pytest.mark.parametrize("L", [1, 7, 50, 61, 769, 790, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8192])
+@pytest.mark.parametrize("L", [1, 7, 50, 61, 769, 790, 800, 882, 1000, 1008, 1023, 1025, 1500, 3000, 4160, 8256, 8704])
 def test_spectrum_window_callback_lengths(bd, oracle, L):
     """Callback lengths that are not multiples of 64 (or lie above 4096): the window kernel, with the
     callbacks whose ring starts before the stream on the generic kernel; streams of one callback, of a
@@ -250,8 +281,10 @@ def test_spectrum_granule_callback_lengths(bd, oracle, knobs, L):
     """Multiples of 64 other than 512 / 1024, of 32 up to 512 and of 16 up to 256: the granule kernel
     (granules of 64, 32, 16 samples); short streams, partial steps,
     a stream long enough to be split into runs, and the generic kernel on the same data.  (With three
-    bins or fewer the split kernel takes 129 .. 767 samples off the 64-sample grid by default: switched off here.)"""
+    bins or fewer the split kernel takes 129 .. 767 samples off the 64-sample grid by default, and the half-block
+    kernel the multiples of 512: both switched off here.)"""
     knobs.set("BD_SPEC_NO_SPLIT", "1")
+    knobs.set("BD_SPEC_FORCE_GRANULE", "1")
     for n, streams in ((40000, 3), (4096 * 3 + L * 2 + 17, 2), (max(L, 100), 2), (4096 * 40 + 5, 1)):
         x = _synth(bd, streams, n, first=3)
         res, ref_v, _, _ = _compare(bd, oracle, "Spectrum", SR, x, L)
@@ -265,7 +298,8 @@ def test_spectrum_granule_callback_lengths(bd, oracle, knobs, L):
 
 def test_spectrum_granule_equals_generic(bd, oracle, knobs):
     import torch
-    knobs.set("BD_SPEC_NO_SPLIT", "1")     # 480 and 240 would take the split kernel
+    knobs.set("BD_SPEC_NO_SPLIT", "1")     # 480 and 240 would take the split kernel,
+    knobs.set("BD_SPEC_FORCE_GRANULE", "1")    # 2048 the half-block kernel
     x = torch.from_numpy(np.ascontiguousarray(np.pad(_synth(bd, 4, 4096 * 9 + 100, first=1), ((0, 0), (0, 28))))).cuda()
     n = 4096 * 9 + 100
     for L in (256, 2048, 704, 480, 240):
@@ -641,7 +675,7 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
     view[:, :n] = torch.from_numpy(x).cuda()
     assert view.data_ptr() % 4 == 2
     for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
-                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_split_kernel"),
+                                 ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 3072, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_split_kernel"),
                                  ("Spectrum", 819, "bd_spectrum_g63_kernel"),
                                  ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
         kind = bd.StrategyKind[kind_name]
