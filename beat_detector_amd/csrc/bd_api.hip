@@ -101,7 +101,7 @@ static std::mutex bd_tuning_mutex;
 static const bd_tuning *bd_tuning_read()
 {
     auto num = [](const char *name) -> long long { const char *v = getenv(name); return v ? atoll(v) : 0; };
-    auto set = [](const char *name) -> int { return getenv(name) != nullptr; };
+    auto set = [](const char *name) -> int { const char *v = getenv(name); return v && *v && strcmp(v, "0") != 0; };   // "", "0": off
     bd_tuning *t = new bd_tuning();
     t->spec_force_granule = set("BD_SPEC_FORCE_GRANULE");
     t->spec_run = (int)num("BD_SPEC_RUN");
