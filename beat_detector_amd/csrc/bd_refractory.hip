@@ -11,7 +11,7 @@
 // a decision at callback j becomes a beat unless beat_time > 0 and
 // beat_time < last_beat + gap (last_beat starts at 0, so nothing fires before
 // `gap` ms).  One wavefront per stream reads 64 decisions per step (coalesced),
-// sixteen steps ahead, turns each step's into a 64-bit mask and walks the set bits.
+// turns them into a 64-bit mask and walks the set bits.
 #include "bd_internal.h"
 
 __global__ __launch_bounds__(256) void bd_refractory_kernel(
@@ -30,38 +30,27 @@ __global__ __launch_bounds__(256) void bd_refractory_kernel(
         n_cb = own < n_cb_max ? own : n_cb_max;
     }
     uint32_t last_beat = 0, count = 0;
-    // The pass is bound by the latency of its loads (a stream's decisions are a few KB): the loads of
-    // BD_REFR_AHEAD steps are issued together, then their masks are walked in order.
-    constexpr int BD_REFR_AHEAD = 16;
-    for (uint64_t base0 = 0; base0 < n_cb; base0 += 64 * BD_REFR_AHEAD) {
-        uint8_t v[BD_REFR_AHEAD];
-#pragma unroll
-        for (int k = 0; k < BD_REFR_AHEAD; k++) {
-            const uint64_t j = base0 + 64 * k + lane;
-            v[k] = j < n_cb ? f[j] : (uint8_t)0;
-        }
-#pragma unroll
-        for (int k = 0; k < BD_REFR_AHEAD; k++) {
-            const uint64_t base = base0 + 64 * k;
-            unsigned long long mask = __ballot(v[k] != 0);
-            while (mask) { // wave-uniform
-                const int b = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const uint64_t jj = base + (uint64_t)b;
-                const uint32_t beat_time = (uint32_t)jj * step_ms + half_ms; // wraps like u32 adds
-                bool allowed = true;
-                if (beat_time > 0) {                                // lib.rs:120
-                    const uint32_t threshold = last_beat + gap_ms;  // lib.rs:121
-                    if (beat_time < threshold) allowed = false;     // lib.rs:122-124
+    for (uint64_t base = 0; base < n_cb; base += 64) {
+        const uint64_t j = base + lane;
+        const bool set = (j < n_cb) && (f[j] != 0);
+        unsigned long long mask = __ballot(set);
+        while (mask) { // wave-uniform
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const uint64_t jj = base + (uint64_t)b;
+            const uint32_t beat_time = (uint32_t)jj * step_ms + half_ms; // wraps like u32 adds
+            bool allowed = true;
+            if (beat_time > 0) {                                // lib.rs:120
+                const uint32_t threshold = last_beat + gap_ms;  // lib.rs:121
+                if (beat_time < threshold) allowed = false;     // lib.rs:122-124
+            }
+            if (allowed) {
+                if (lane == 0 && count < max_beats) {
+                    if (beat_idx) beat_idx[s * max_beats + count] = (uint32_t)jj;
+                    if (beat_ms) beat_ms[s * max_beats + count] = beat_time;
                 }
-                if (allowed) {
-                    if (lane == 0 && count < max_beats) {
-                        if (beat_idx) beat_idx[s * max_beats + count] = (uint32_t)jj;
-                        if (beat_ms) beat_ms[s * max_beats + count] = beat_time;
-                    }
-                    count++;
-                    last_beat = beat_time;                          // mod.rs:89-91
-                }
+                count++;
+                last_beat = beat_time;                          // mod.rs:89-91
             }
         }
     }
