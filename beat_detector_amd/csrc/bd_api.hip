@@ -116,6 +116,7 @@ static const bd_tuning *bd_tuning_read()
     t->split_stage = (int)num("BD_SPLIT_STAGE");
     t->split_subruns = (int)num("BD_SPLIT_SUBRUNS");
     t->lpf_variant = (int)num("BD_LPF_VARIANT");
+    t->lpf_groups = (int)num("BD_LPF_GROUPS");
     const long long thr = num("BD_HOST_THREADS");
     t->host_threads = thr > 0 ? (unsigned)thr : 0u;
     const long long chunk = num("BD_HOST_CHUNK_BYTES");

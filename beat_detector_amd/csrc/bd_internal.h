@@ -53,6 +53,7 @@ struct bd_tuning {
     int      split_subruns;          // BD_SPLIT_SUBRUNS: runs of 64 callbacks per wavefront of the split kernel (0 = automatic)
     int      split_stage;            // BD_SPLIT_STAGE: 1 = every length through the staged copy, 2 = rows straight from memory wherever possible
     int      lpf_variant;            // BD_LPF_VARIANT: chunk size / wavefronts per workgroup
+    int      lpf_groups;             // BD_LPF_GROUPS: groups of 64 windows per wavefront (aligned staging), 0 = chosen by the launcher
     unsigned host_threads;           // BD_HOST_THREADS: packing threads of bd_analyze_batch_host (0 = default)
     uint64_t host_chunk_bytes;       // BD_HOST_CHUNK_BYTES: staging chunk of bd_analyze_batch_host (0 = default)
 };

@@ -26,8 +26,10 @@ struct bd_lpf_args {
     uint64_t       stride;      // samples between streams
     uint64_t       n_cb;        // callbacks per stream
     uint64_t       out_stride;  // callbacks between the rows of values / flags
-    uint64_t       n_tasks;     // n_streams * groups_per_stream
+    uint64_t       n_tasks;     // n_streams * tasks_per_stream
     uint32_t       groups_per_stream; // ceil(n_cb / 64)
+    uint32_t       groups_per_task;   // consecutive groups of 64 windows one wavefront walks (aligned staging)
+    uint32_t       tasks_per_stream;  // ceil(groups_per_stream / groups_per_task)
     uint32_t       callback_len;
     uint32_t       min_amp;
     float          alpha;
@@ -80,10 +82,12 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     uint4 *tile = tile_all[wave];
     const uint64_t task = bd_block_index() * WPB + wave;
     if (task >= a.n_tasks) return; // wave-uniform
-    const uint64_t s = task / a.groups_per_stream;
-    const uint64_t j0 = (task - s * a.groups_per_stream) * 64;
+    const uint64_t s = task / a.tasks_per_stream;
+    const uint32_t g0 = (uint32_t)(task - s * a.tasks_per_stream) * a.groups_per_task;   // first group of the task
+    const uint32_t n_groups = a.groups_per_stream - g0 < a.groups_per_task ? a.groups_per_stream - g0 : a.groups_per_task;
+    const uint64_t j0 = (uint64_t)g0 * 64;
     const uint32_t L = a.callback_len;
-    const int16_t *gp = a.samples + s * a.stride + j0 * L; // first window of the group
+    const int16_t *gp = a.samples + s * a.stride + j0 * L; // first window of the first group
     const uint64_t rows = (a.n_cb - j0 < 64) ? (a.n_cb - j0) : 64;
     // Chunk boundaries are placed on 128-byte lines of memory: when the rows do
     // not start on a line (possible when callback_len % 64 == 0 makes all windows
@@ -106,42 +110,56 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
         // 16-byte piece lane % PIECES: CHUNK * 2 contiguous bytes per window
         const int lrow = lane / PIECES, piece = lane % PIECES;
         uint4 stage[PIECES];
-        auto load_chunk = [&](uint32_t ch) {
+        // A task is a run of groups (64 windows each) of one stream, walked as one sequence of steps
+        // (group, chunk): the loads of the next step -- the next chunk, or the first chunk of the next
+        // group -- are in flight while this one is filtered, so short windows (one or two chunks per
+        // group) keep the pipeline of long ones.
+        auto load_chunk = [&](uint32_t g, uint32_t ch) {
             const uint32_t first = chunk_start(ch) + piece * 8; // sample offset inside the window
             const uint32_t end = chunk_end(ch);
+            const uint64_t jg = j0 + (uint64_t)g * 64;
+            const uint64_t rows_g = (a.n_cb - jg < 64) ? (a.n_cb - jg) : 64;
+            const int16_t *gpg = gp + (uint64_t)g * 64 * L;
 #pragma unroll
             for (int i = 0; i < PIECES; i++) {
                 const uint32_t row = ROWS_PER_LOAD * i + lrow;
-                if (row < rows && first < end)
-                    stage[i] = bd_load_stream16(gp + (uint64_t)row * L + first);
+                if (row < rows_g && first < end)
+                    stage[i] = bd_load_stream16(gpg + (uint64_t)row * L + first);
                 else
                     stage[i] = make_uint4(0, 0, 0, 0);
             }
         };
-        load_chunk(0);
-        for (uint32_t ch = 0; ch < n_chunks; ch++) {
-            // all lanes have finished reading the previous chunk (LDS operations of
-            // one wavefront complete in order); keep the compiler from reordering
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+        load_chunk(0, 0);
+        for (uint32_t g = 0; g < n_groups; g++) {
+            for (uint32_t ch = 0; ch < n_chunks; ch++) {
+                // all lanes have finished reading the previous chunk (LDS operations of
+                // one wavefront complete in order); keep the compiler from reordering
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int i = 0; i < PIECES; i++)
-                tile[(ROWS_PER_LOAD * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
-            if (ch + 1 < n_chunks) load_chunk(ch + 1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int pieces = (int)((chunk_end(ch) - chunk_start(ch)) / 8);
-            for (int p = 0; p < pieces; p++) {
-                const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
-                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                for (int i = 0; i < PIECES; i++)
+                    tile[(ROWS_PER_LOAD * i + lrow) * BD_LPF_ROW_U4 + piece] = stage[i];
+                if (ch + 1 < n_chunks) load_chunk(g, ch + 1);
+                else if (g + 1 < n_groups) load_chunk(g + 1, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int pieces = (int)((chunk_end(ch) - chunk_start(ch)) / 8);
+                for (int p = 0; p < pieces; p++) {
+                    const uint4 v = tile[lane * BD_LPF_ROW_U4 + p];
+                    const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int d = (int)w[q];
-                    bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
-                    bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    for (int q = 0; q < 4; q++) {
+                        const int d = (int)w[q];
+                        bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                        bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    }
                 }
             }
+            const uint64_t jg = j0 + (uint64_t)g * 64;
+            bd_lpf_finish(a, s, jg, (unsigned)((a.n_cb - jg < 64) ? (a.n_cb - jg) : 64), lane, xmax, ymax);
+            y = 0.f; ymax = 0.f; xmax = 0.f;      // the filter restarts in every window (lpf.rs:66)
         }
+        return;
     } else {
         // Rows at any 2-byte-aligned address (callback length not a multiple of 64, odd strides):
         // every row is cut at the SEG-byte lines of memory it crosses, so that a line is fetched
@@ -250,6 +268,7 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     const uint64_t groups = (n_cb + 63) / 64;
     if (groups > 0xffffffffull) { bd_set_error("stream too long"); return BD_ERR_UNSUPPORTED; }
     a.groups_per_stream = (uint32_t)groups;
+    a.groups_per_task = 1; a.tasks_per_stream = (uint32_t)groups;
     a.n_tasks = n_streams * groups;
     a.callback_len = callback_len; a.min_amp = plan.min_amp;
     a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
@@ -263,6 +282,19 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     const int variant_env = bd_tuning_get().lpf_variant;
     const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
     const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
+    if (aligned) {
+        // Windows of up to 128 samples: a wavefront walks 256 / L groups of 64 windows (8,192 streams x 60 s:
+        // 64 samples 4.25 -> 4.9 TB/s with four groups, 128 samples 5.4 -> 5.85 with two; from 192 samples on one
+        // group per wavefront is as fast or faster), fewer where the batch would leave CUs without work.
+        uint32_t gpt = callback_len <= 128 ? 256 / callback_len : 1;
+        if (gpt > 8) gpt = 8;
+        while (gpt > 1 && n_streams * ((groups + gpt - 1) / gpt) < 32768) gpt >>= 1;
+        const int knob = bd_tuning_get().lpf_groups;
+        if (knob >= 1 && knob <= 64) gpt = (uint32_t)knob;
+        a.groups_per_task = gpt;
+        a.tasks_per_stream = (uint32_t)((groups + gpt - 1) / gpt);
+        a.n_tasks = n_streams * a.tasks_per_stream;
+    }
     const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;
     dim3 grid_dims;
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }

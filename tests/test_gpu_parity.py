@@ -395,6 +395,26 @@ def test_lpf_ragged(bd, oracle, L):
         _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 
 
+@pytest.mark.parametrize("L", [8, 16, 24, 32, 48, 64, 96, 104, 128, 192, 1024])
+def test_lpf_several_groups_per_wavefront(bd, oracle, knobs, L):
+    """Short windows: a wavefront walks several groups of 64 windows in a row (chosen by the launcher; forced to
+    1, 2, 3, 8 and 64 here).  Streams of one window, of a partial group, of whole groups and a partial one, of more
+    groups than one wavefront takes; a lowered threshold so that short windows fire too."""
+    kw = dict(lpf_ratio=0.05, min_amplitude=100)
+    for n, streams in ((L, 2), (L * 37 + 3, 3), (L * 64 * 5 + L * 17 + 1, 2), (L * 64 * 21 + 5, 1)):
+        x = _synth(bd, streams, n, first=13)
+        for groups in (None, 1, 2, 3, 8, 64):
+            if groups is None:
+                knobs.unset("BD_LPF_GROUPS")
+            else:
+                knobs.set("BD_LPF_GROUPS", str(groups))
+            _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+            _, _, ref_c, _ = _compare(bd, oracle, "LPF", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw),
+                                      exact_values=True)
+        assert ref_c.sum() > 0 or n == L       # the lowered threshold lets short windows fire
+    knobs.unset("BD_LPF_GROUPS")
+
+
 def test_lpf_many_windows_per_stream(bd, oracle):
     # more than 64 windows per stream, not a multiple of 64; odd stream count
     x = _synth(bd, 7, 1024 * 131 + 77, first=100)
