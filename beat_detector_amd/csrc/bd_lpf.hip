@@ -288,6 +288,9 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
         // group per wavefront is as fast or faster), fewer where the batch would leave CUs without work.
         uint32_t gpt = callback_len <= 128 ? 256 / callback_len : 1;
         if (gpt > 8) gpt = 8;
+        // (windows of 2,048 samples -- rows 4 KB apart -- are the one longer length that gains from two groups:
+        // 6.0 -> 6.35 TB/s at 4,096 streams, 6.2 -> 6.5 at 8,192, 6.35 -> 6.6 at 16,384; 1,024 and 4,096 lose 2 %)
+        if (callback_len == 2048) gpt = 2;
         while (gpt > 1 && n_streams * ((groups + gpt - 1) / gpt) < 32768) gpt >>= 1;
         const int knob = bd_tuning_get().lpf_groups;
         if (knob >= 1 && knob <= 64) gpt = (uint32_t)knob;
