@@ -395,7 +395,7 @@ def test_lpf_ragged(bd, oracle, L):
         _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 
 
-@pytest.mark.parametrize("L", [8, 16, 24, 32, 48, 64, 96, 104, 128, 192, 1024])
+@pytest.mark.parametrize("L", [8, 16, 24, 32, 48, 64, 96, 104, 128, 192, 1024, 2048])
 def test_lpf_several_groups_per_wavefront(bd, oracle, knobs, L):
     """Short windows: a wavefront walks several groups of 64 windows in a row (chosen by the launcher; forced to
     1, 2, 3, 8 and 64 here).  Streams of one window, of a partial group, of whole groups and a partial one, of more
