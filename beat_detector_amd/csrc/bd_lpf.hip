@@ -252,6 +252,143 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_window_kernel(bd_lpf_args a)
     bd_lpf_finish(a, s, j0, (unsigned)rows, lane, xmax, ymax);
 }
 
+
+// Line staging for rows at any 2-byte-aligned address, callback lengths from 64 samples to 2^22:
+// the scheme of the ALIGNED = false branch above -- chunk `ch` of a row is the ch-th 128-byte line of
+// memory the row touches, read with aligned 16-byte loads, a lane filters its window's samples
+// [lo, hi) of the line -- with two changes that matter where callbacks are a few hundred samples long
+// (441: the kernel above issued 12.2 VALU instructions per sample, 7.3 of them the filter, and fetched
+// 14 % more bytes than the samples):
+//  * addresses are 32-bit offsets from the line that holds the group's first sample, kept per lane and
+//    load slot; loads go through a buffer descriptor over the group's bytes, so a row past the end of
+//    the stream is an out-of-range offset (dropped, zeros) instead of a branch, and only the first and
+//    the last two lines of a row evaluate per-piece conditions;
+//  * KEEP: the line in which row r ends is the line in which row r + 1 begins (unless r + 1 starts on a
+//    line); fetched for both, several lines apart in time, it travels from memory twice.  The first line of
+//    every row stays in registers and is handed to the row before it when that row reaches its last
+//    line; only the last row of a group reads its last line from memory.
+// A 16-byte piece that holds at least one sample of the analysed stream is loaded whole: it lies inside
+// one 128-byte line with that sample, so the bytes of it before the stream's first or after its last
+// analysed sample are readable, and the filter's [lo, hi) never looks at them.
+template <bool KEEP, int WPB>
+__global__ __launch_bounds__(64 * WPB) void bd_lpf_lines_kernel(bd_lpf_args a)
+{
+    constexpr uint32_t CH = 64, SEG = 128, PIECES = 8, ROW_U4 = PIECES + 1, ROWS_PER_LOAD = 8;
+    constexpr uint32_t DROPPED = 0x80000000u; // an offset beyond every descriptor
+    __shared__ uint4 tile_all[WPB][64 * ROW_U4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint4 *tile = tile_all[wave];
+    const uint64_t task = bd_block_index() * WPB + wave;
+    if (task >= a.n_tasks) return; // wave-uniform
+    const uint64_t s = task / a.groups_per_stream;
+    const uint64_t j0 = (task - s * a.groups_per_stream) * 64;
+    const uint32_t L = a.callback_len;
+    const uint32_t rows = (a.n_cb - j0 < 64) ? (uint32_t)(a.n_cb - j0) : 64u;
+    const char *g_ptr = reinterpret_cast<const char *>(a.samples + s * a.stride + j0 * L); // the group's first sample
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(g_ptr) & (SEG - 1)));
+    const uint64_t base = reinterpret_cast<uintptr_t>(g_ptr) - c0;                          // its line
+    const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    const uint32_t n_rec = __builtin_amdgcn_readfirstlane((c0 + 2u * rows * L + 15u) & ~15u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>((uintptr_t)(((uint64_t)b_hi << 32) | b_lo)), 0, (int)n_rec, 0x00020000);
+    const uint32_t lrow = (uint32_t)lane / PIECES, piece = (uint32_t)lane % PIECES;
+    const uint32_t n_lines = (L + 2 * CH - 2) / CH; // lines a row can touch; it touches n_lines - 1 or n_lines
+
+    // load slot i of this lane: piece `piece` of the lines of row 8 i + lrow; positions are bytes from `base`
+    uint32_t o[PIECES];
+#pragma unroll
+    for (uint32_t i = 0; i < PIECES; i++) {
+        const uint32_t row = ROWS_PER_LOAD * i + lrow;
+        o[i] = row < rows ? ((c0 + 2u * row * L) & ~(SEG - 1)) + 16u * piece : DROPPED;
+    }
+    uint4 stage[PIECES], keep[KEEP ? PIECES : 1];
+    auto load_chunk = [&](uint32_t ch) {
+        if (ch > 0 && ch + 2 < n_lines) { // lines that lie inside their rows
+#pragma unroll
+            for (uint32_t i = 0; i < PIECES; i++) {
+                const bd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, o[i] + SEG * ch, 0, 2 /* nt */);
+                stage[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < PIECES; i++) {
+                const uint32_t row = ROWS_PER_LOAD * i + lrow;
+                const uint32_t ra = c0 + 2u * row * L, re = ra + 2u * L;
+                const uint32_t la = (ra & ~(SEG - 1)) + SEG * ch, pa = la + 16u * piece;
+                // pieces that hold samples of the row; the first line of a row that hands it on is loaded whole
+                bool want = row < rows && pa < re && (pa + 16u > ra || (KEEP && ch == 0 && row >= 1));
+                // the last line comes from the row after this one
+                if (KEEP && ch > 0 && row + 1 < rows && la + SEG > re) want = false;
+                const bd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, want ? pa : DROPPED, 0, 2 /* nt */);
+                stage[i] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    // this lane's window inside its lines
+    const uint32_t off = ((c0 + 2u * (uint32_t)lane * L) & (SEG - 1)) / 2;
+    const uint32_t len = (uint32_t)lane < rows ? L : 0;
+    float y = 0.f, ymax = 0.f, xmax = 0.f;
+    const float alpha = a.alpha;
+    load_chunk(0);
+    if (KEEP) {
+#pragma unroll
+        for (uint32_t i = 0; i < PIECES; i++) keep[i] = stage[i];
+    }
+    for (uint32_t ch = 0; ch < n_lines; ch++) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t i = 0; i < PIECES; i++)
+            tile[(ROWS_PER_LOAD * i + lrow) * ROW_U4 + piece] = stage[i];
+        if (KEEP && ch + 2 >= n_lines) {
+            // a row's last line is its line n_lines - 2 or n_lines - 1 (these stores follow the ones above
+            // in program order and win)
+#pragma unroll
+            for (uint32_t i = 0; i < PIECES; i++) {
+                const uint32_t row = ROWS_PER_LOAD * i + lrow;
+                const uint32_t ra = c0 + 2u * row * L;
+                if (row >= 1 && row < rows && (ra & (SEG - 1)) != 0 && ra / SEG - (ra - 2u * L) / SEG == ch)
+                    tile[(row - 1) * ROW_U4 + piece] = keep[i];
+            }
+        }
+        if (ch + 1 < n_lines) load_chunk(ch + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t p0 = ch * CH;                                  // first line position of the chunk
+        const uint32_t lo = off > p0 ? off - p0 : 0;
+        const uint32_t end = off + len;                               // line position after the window
+        const uint32_t hi = end > p0 ? (end - p0 < CH ? end - p0 : CH) : 0;
+        const bool whole = lo == 0 && hi == CH;
+        if (__builtin_amdgcn_ballot_w64(!whole) == 0) {
+            for (uint32_t p = 0; p < PIECES; p++) {
+                const uint4 v = tile[lane * ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
+        } else {
+            const uint32_t span = hi > lo ? hi - lo : 0;
+            for (uint32_t p = 0; p < PIECES; p++) {
+                const uint4 v = tile[lane * ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t rel = 8 * p - lo;                       // position - lo (wraps below lo)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    if (rel + 2 * q < span) bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    if (rel + 2 * q + 1 < span) bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
+        }
+    }
+    bd_lpf_finish(a, s, j0, rows, lane, xmax, ymax);
+}
+
 int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_streams,
                   uint64_t n_samples, uint64_t stride, uint32_t callback_len,
                   float *values, uint8_t *flags, uint64_t out_stride, hipStream_t st)
@@ -274,13 +411,17 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
     // Rows that keep their place inside a 128-byte line (callback length a multiple of 64) use the
     // aligned staging; so do short callbacks, where the partial first and last lines of the line
-    // staging weigh more than the lines it saves (160: 4.7 vs 4.6 TB/s; 480: 5.3 vs 6.1; 1000: 4.8 vs 6.1).
+    // staging weigh more than the lines it saves (4,096 x 60 s: 120 samples 5.9 vs 3.8 TB/s, 144: 4.7 vs 4.3,
+    // 160: 4.65 both, 176: 4.3 vs 4.8, 200: 4.3 vs 5.0, 248: 4.7 vs 5.4).
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0) &&
-                         (callback_len % 64 == 0 || callback_len < 256);
+                         (callback_len % 64 == 0 || callback_len <= 160);
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
     const int variant_env = bd_tuning_get().lpf_variant;
-    const int variant = variant_env == 0 ? 2 : (variant_env == 3 ? 0 : variant_env);
+    // (64-sample chunks where the window is no longer than one, 4,096 x 60 s: 16 samples 2.25 -> 4.15 TB/s,
+    // 32: 3.8 -> 5.2, 48: 4.5 -> 5.3, 64: 5.1 -> 5.6; and at 192 and 256 samples: 6.1 -> 6.2, 6.3 -> 6.4)
+    const bool chunk64 = callback_len <= 64 || callback_len == 192 || callback_len == 256;
+    const int variant = variant_env == 0 ? (chunk64 ? 0 : 2) : (variant_env == 3 ? 0 : variant_env);
     const int wpb = (aligned && variant == 1) ? 1 : (aligned && variant == 2) ? 2 : 4;
     if (aligned) {
         // Windows of up to 128 samples: a wavefront walks 256 / L groups of 64 windows (8,192 streams x 60 s:
@@ -301,7 +442,17 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     const uint64_t grid64 = (a.n_tasks + wpb - 1) / wpb;
     dim3 grid_dims;
     if (!bd_grid_dims(grid64, &grid_dims)) { bd_set_error("batch too large for one launch"); return BD_ERR_UNSUPPORTED; }
-    if (!aligned)
+    const char *kernel_name = "bd_lpf_window_kernel";
+    if (!aligned && callback_len >= 64 && callback_len < (1u << 22)) {
+        if (variant_env != 6) kernel_name = "bd_lpf_lines_kernel";
+        // BD_LPF_VARIANT 5: every line from memory; 6: the kernel with per-piece 64-bit addressing
+        if (variant_env == 5)
+            hipLaunchKernelGGL((bd_lpf_lines_kernel<false, 4>), grid_dims, dim3(256), 0, st, a);
+        else if (variant_env == 6)
+            hipLaunchKernelGGL((bd_lpf_window_kernel<false, 64, 4>), grid_dims, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((bd_lpf_lines_kernel<true, 4>), grid_dims, dim3(256), 0, st, a);
+    } else if (!aligned)
         hipLaunchKernelGGL((bd_lpf_window_kernel<false, 64, 4>), grid_dims, dim3(256), 0, st, a);
     else if (variant == 1)
         hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 1>), grid_dims, dim3(64), 0, st, a);
@@ -309,6 +460,6 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
         hipLaunchKernelGGL((bd_lpf_window_kernel<true, 128, 2>), grid_dims, dim3(128), 0, st, a);
     else
         hipLaunchKernelGGL((bd_lpf_window_kernel<true, 64, 4>), grid_dims, dim3(256), 0, st, a);
-    bd_set_last_kernel("bd_lpf_window_kernel");
-    return bd_check_hip(hipGetLastError(), "launch bd_lpf_window_kernel");
+    bd_set_last_kernel(kernel_name);
+    return bd_check_hip(hipGetLastError(), "launch LPF kernel");
 }

@@ -395,6 +395,33 @@ def test_lpf_ragged(bd, oracle, L):
         _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 
 
+@pytest.mark.parametrize("L", [64 + 1, 66, 100, 168, 200, 248, 264, 441, 500, 529, 540, 1000, 2001])
+def test_lpf_line_staging_layouts(bd, oracle, L):
+    """The line-staging kernel (callbacks off the 64-sample grid, 64 samples and longer): stream rows that start at
+    every kind of position inside a 128-byte line (odd and even strides, odd base offsets), so that rows begin on a
+    line, one sample before or after one, and anywhere between; groups of exactly 64, 65 and 127 windows, one
+    window, and garbage after the analysed samples of every stream -- the line a row shares with the next row is
+    handed over in registers, the last row's comes from memory and must not look past the stream."""
+    torch = _torch()
+    rng = np.random.default_rng(L)
+    for n_cb, streams in ((64, 3), (65, 2), (127, 2), (1, 3), (200, 2)):
+        n = n_cb * L + int(rng.integers(0, L))
+        x = _synth(bd, streams, n, first=int(rng.integers(1, 1000)))
+        ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_LPF, SR, x, L)
+        for base_off, pad in ((0, 0), (1, 3), (63, 64), (64, 1), (5, 70)):
+            stride = n + pad
+            flat = torch.from_numpy(rng.integers(-32768, 32768, base_off + streams * stride + 64).astype(np.int16)).cuda()
+            view = flat[base_off:base_off + streams * stride].view(streams, stride)
+            view[:, :n] = torch.from_numpy(x).cuda()
+            res = bd.analyze_batch(bd.StrategyKind.LPF, SR, view, L, n_samples=n)
+            torch.cuda.synchronize()
+            assert bd.last_kernel_name() == "bd_lpf_lines_kernel"
+            np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
+            np.testing.assert_array_equal(res.values.cpu().numpy(), ref_v)
+            for s in range(streams):
+                assert res.beats(s) == ref_b[s]
+
+
 @pytest.mark.parametrize("L", [8, 16, 24, 32, 48, 64, 96, 104, 128, 192, 1024, 2048])
 def test_lpf_several_groups_per_wavefront(bd, oracle, knobs, L):
     """Short windows: a wavefront walks several groups of 64 windows in a row (chosen by the launcher; forced to
@@ -697,7 +724,8 @@ def test_rows_that_are_only_2_byte_aligned(bd, oracle):
     for kind_name, L, kernel in (("Spectrum", 512, "bd_spectrum_granule_kernel"), ("Spectrum", 1024, "bd_spectrum_granule_kernel"),
                                  ("Spectrum", 2048, "bd_spectrum_granule_kernel"), ("Spectrum", 3072, "bd_spectrum_granule_kernel"), ("Spectrum", 441, "bd_spectrum_split_kernel"),
                                  ("Spectrum", 819, "bd_spectrum_g63_kernel"),
-                                 ("LPF", 1024, "bd_lpf_window_kernel"), ("LPF", 441, "bd_lpf_window_kernel")):
+                                 ("LPF", 1024, "bd_lpf_lines_kernel"), ("LPF", 441, "bd_lpf_lines_kernel"),
+                                 ("LPF", 50, "bd_lpf_window_kernel")):
         kind = bd.StrategyKind[kind_name]
         okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
         res = bd.analyze_batch(kind, SR, view, L, n_samples=n)
@@ -751,6 +779,10 @@ def test_tuning_knobs_do_not_change_results(bd, oracle, knobs):
     for variant in ("1", "2", "3"):
         knobs.set("BD_LPF_VARIANT", variant)
         for L in (1024, 64, 4096, 136):
+            _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+    for variant in ("5", "6"):              # line staging: every line from memory / per-piece addressing
+        knobs.set("BD_LPF_VARIANT", variant)
+        for L in (441, 65, 200, 1000):
             _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
 
 
