@@ -132,9 +132,22 @@ __device__ __forceinline__ uint4 bd_load_stream16(const void *p)
 // so stores go through a buffer descriptor over the wavefront's output range
 // [base, base + bytes): `base` must be wave-uniform.
 #define BD_AUX_STREAM_STORE 18 /* nt (2) | sc1 (16) */
+// A descriptor over [base, base + bytes), both the same in every lane of the wavefront.  Its four
+// dwords go through readfirstlane: a base that the compiler keeps in vector registers (anything
+// computed with a 64-bit division, for one) otherwise wraps every access in a loop over the distinct
+// descriptors of the wavefront -- four readfirstlanes, two 64-bit compares and a branch per access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bd_uniform_rsrc(const void *base, unsigned bytes)
+{
+    const uint64_t b = reinterpret_cast<uintptr_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+    const uint32_t n = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>((uintptr_t)(((uint64_t)hi << 32) | lo)), 0, (int)n,
+                                             0x00020000);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t bd_out_rsrc(void *base, unsigned bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+    return bd_uniform_rsrc(base, bytes);
 }
 __device__ __forceinline__ void bd_store_stream_f32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v)
 {

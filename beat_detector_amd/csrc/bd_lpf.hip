@@ -51,6 +51,20 @@ __device__ __forceinline__ void bd_lpf_step(float x, float alpha, float &y, floa
     xmax = fmaxf(xmax, fabsf(x));
 }
 
+// The same step for code under a per-lane predicate.  After a divergent branch the compiler no longer
+// knows that the running maxima are canonical numbers and puts a v_max_f32 v, v, v in front of every
+// fmaxf (two more instructions per sample); written as the instruction itself, which skips a NaN
+// operand exactly as fmaxf does, none is needed.
+__device__ __forceinline__ void bd_lpf_step_masked(float x, float alpha, float &y, float &ymax, float &xmax)
+{
+    const float d = x - y;
+    const float m = alpha * d;
+    const float s = y + m;
+    y = truncf(s);
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(ymax) : "v"(ymax), "v"(y));
+    asm("v_max_f32 %0, %1, |%2|" : "=v"(xmax) : "v"(xmax), "v"(x));
+}
+
 // `j0` is the first window of the wavefront's group, `rows` the number of valid lanes
 __device__ __forceinline__ void bd_lpf_finish(const bd_lpf_args &a, uint64_t s, uint64_t j0, unsigned rows, int lane,
                                               float xmax, float ymax)
@@ -286,12 +300,7 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_lines_kernel(bd_lpf_args a)
     const uint32_t rows = (a.n_cb - j0 < 64) ? (uint32_t)(a.n_cb - j0) : 64u;
     const char *g_ptr = reinterpret_cast<const char *>(a.samples + s * a.stride + j0 * L); // the group's first sample
     const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(reinterpret_cast<uintptr_t>(g_ptr) & (SEG - 1)));
-    const uint64_t base = reinterpret_cast<uintptr_t>(g_ptr) - c0;                          // its line
-    const uint32_t b_lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t b_hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    const uint32_t n_rec = __builtin_amdgcn_readfirstlane((c0 + 2u * rows * L + 15u) & ~15u);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>((uintptr_t)(((uint64_t)b_hi << 32) | b_lo)), 0, (int)n_rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = bd_uniform_rsrc(g_ptr - c0, (c0 + 2u * rows * L + 15u) & ~15u); // from its line on
     const uint32_t lrow = (uint32_t)lane / PIECES, piece = (uint32_t)lane % PIECES;
     const uint32_t n_lines = (L + 2 * CH - 2) / CH; // lines a row can touch; it touches n_lines - 1 or n_lines
 
@@ -371,7 +380,34 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_lines_kernel(bd_lpf_args a)
                     bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
                 }
             }
+        } else if (ch == 0 && n_lines > 2) {
+            // the first line of rows of more than a line: a lane's samples are those from `lo` on
+#pragma unroll
+            for (uint32_t p = 0; p < PIECES; p++) {
+                const uint4 v = tile[lane * ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    if (lo <= 8 * p + 2 * q) bd_lpf_step_masked((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    if (lo <= 8 * p + 2 * q + 1) bd_lpf_step_masked((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
+        } else if (ch > 0 && n_lines > 2) {
+            // a row's last line (or, for lanes whose row ends in the next line, a whole one): the samples before `hi`
+#pragma unroll
+            for (uint32_t p = 0; p < PIECES; p++) {
+                const uint4 v = tile[lane * ROW_U4 + p];
+                const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const int d = (int)w[q];
+                    if (8 * p + 2 * q < hi) bd_lpf_step_masked((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    if (8 * p + 2 * q + 1 < hi) bd_lpf_step_masked((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                }
+            }
         } else {
+            // rows of 64 or 65 samples: a line can hold a row's first and last sample
             const uint32_t span = hi > lo ? hi - lo : 0;
             for (uint32_t p = 0; p < PIECES; p++) {
                 const uint4 v = tile[lane * ROW_U4 + p];
@@ -380,8 +416,8 @@ __global__ __launch_bounds__(64 * WPB) void bd_lpf_lines_kernel(bd_lpf_args a)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int d = (int)w[q];
-                    if (rel + 2 * q < span) bd_lpf_step((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
-                    if (rel + 2 * q + 1 < span) bd_lpf_step((float)(short)(d >> 16), alpha, y, ymax, xmax);
+                    if (rel + 2 * q < span) bd_lpf_step_masked((float)(short)(d & 0xffff), alpha, y, ymax, xmax);
+                    if (rel + 2 * q + 1 < span) bd_lpf_step_masked((float)(short)(d >> 16), alpha, y, ymax, xmax);
                 }
             }
         }

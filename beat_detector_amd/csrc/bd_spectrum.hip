@@ -255,8 +255,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // DEPTH register buffers in a ring, each filled DEPTH - 1 iterations ahead of its use.  Rows whose
     // loads were dropped produce sums of zeros that no stored result uses.
     const int64_t hb_end = n_hb < hb0 + (int64_t)a.run_hbs ? n_hb : hb0 + (int64_t)a.run_hbs;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<int16_t *>(sp + hb_lo * BD_HALF_BLOCK), 0, (int)((hb_end - hb_lo) * BD_HALF_BLOCK * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = bd_uniform_rsrc(sp + hb_lo * BD_HALF_BLOCK, (unsigned)((hb_end - hb_lo) * BD_HALF_BLOCK * 2));
     // byte offset of this lane's first piece in iteration 0, counted from half-block hb_lo (negative,
     // i.e. out of range as an unsigned offset, for the rows of iteration -1 before it)
     const int lane_off = (int)(hb0 - hb_lo + g) * (BD_HALF_BLOCK * 2) + 16 * l;

@@ -1,6 +1,6 @@
 """LPF off the 64-sample grid: the line-staging kernels side by side in one process (BD_LPF_VARIANT 6 = per-piece
 64-bit addressing, 5 = 32-bit offsets through a buffer descriptor, default = the same with the shared line kept in
-registers).  Environment: STREAMS, LENGTHS, ROUNDS."""
+registers; a suffix gN sets BD_LPF_GROUPS=N).  Environment: STREAMS, LENGTHS, ROUNDS, VARIANTS."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +17,11 @@ for L in [int(v) for v in os.environ.get("LENGTHS", "441,500,529,540,882,1000,15
     flags = torch.empty((streams, pitch), dtype=torch.uint8, device="cuda")
     for r in range(int(os.environ.get("ROUNDS", "3"))):
         for v in variants:
-            os.environ["BD_LPF_VARIANT"] = v; bd.lib().bd_tuning_reload()
+            os.environ["BD_LPF_VARIANT"], _, groups = v.partition("g")      # "0g4": variant 0, BD_LPF_GROUPS=4
+            os.environ.pop("BD_LPF_GROUPS", None)
+            if groups:
+                os.environ["BD_LPF_GROUPS"] = groups
+            bd.lib().bd_tuning_reload()
             vals.zero_(); flags.zero_()
             res = bd.batch_candidates(bd.StrategyKind.LPF, sr, buf, L, n_samples=n, values=vals, flags=flags)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
