@@ -450,7 +450,8 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     // staging weigh more than the lines it saves (4,096 x 60 s: 120 samples 5.9 vs 3.8 TB/s, 144: 4.7 vs 4.3,
     // 160: 4.65 both, 176: 4.3 vs 4.8, 200: 4.3 vs 5.0, 248: 4.7 vs 5.4).
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0) &&
-                         (callback_len % 64 == 0 || callback_len <= 160);
+                         (callback_len % 64 == 0 || callback_len <= 160) &&
+                         !(bd_tuning_get().lpf_variant == 7 && callback_len >= 64);   // 7: line staging wherever it applies
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
     const int variant_env = bd_tuning_get().lpf_variant;
