@@ -919,7 +919,8 @@ def main() -> None:
         torch.cuda.empty_cache()                   # the chunked pass needs 217 GB of the 288
         also = []
         if also_mode == "all":
-            for w in ("spectrum_1024", "spectrum_529", "lpf", "biquad", "onset_2048", "onset_2048_power"):
+            for w in ("spectrum_1024", "spectrum_529", "spectrum_441", "lpf", "lpf_441", "biquad", "onset_2048",
+                      "onset_2048_power"):
                 r, st_ = run_resident(ctx, w, 3, 1)
                 del st_
                 gc.collect()
