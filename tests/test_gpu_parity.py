@@ -422,6 +422,27 @@ def test_lpf_line_staging_layouts(bd, oracle, L):
                 assert res.beats(s) == ref_b[s]
 
 
+@pytest.mark.parametrize("L,kernel", [(70001, "bd_lpf_lines_kernel"), ((1 << 22) - 1, "bd_lpf_lines_kernel"),
+                                      ((1 << 22) + 1, "bd_lpf_window_kernel")])
+def test_lpf_very_long_windows(bd, oracle, L, kernel):
+    """Windows of tens of thousands to millions of samples: the line-staging kernel addresses a group of windows
+    with 32-bit offsets up to 2^22 samples per window; longer ones take the kernel with 64-bit addresses."""
+    torch = _torch()
+    n = 2 * L + 5
+    x = _synth(bd, 2, n, first=31)
+    ref_v, ref_c, ref_b = util.oracle_batch(oracle, oracle.KIND_LPF, SR, x, L)
+    flat = torch.zeros(3 + 2 * (n + 1), dtype=torch.int16, device="cuda")
+    view = flat[3:3 + 2 * (n + 1)].view(2, n + 1)
+    view[:, :n] = torch.from_numpy(x).cuda()
+    res = bd.analyze_batch(bd.StrategyKind.LPF, SR, view, L, n_samples=n)
+    torch.cuda.synchronize()
+    assert bd.last_kernel_name() == kernel
+    np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c)
+    np.testing.assert_array_equal(res.values.cpu().numpy(), ref_v)
+    for s in range(2):
+        assert res.beats(s) == ref_b[s]
+
+
 @pytest.mark.parametrize("L", [8, 16, 24, 32, 48, 64, 96, 104, 128, 192, 1024, 2048])
 def test_lpf_several_groups_per_wavefront(bd, oracle, knobs, L):
     """Short windows: a wavefront walks several groups of 64 windows in a row (chosen by the launcher; forced to
