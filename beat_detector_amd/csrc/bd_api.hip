@@ -108,6 +108,7 @@ static const bd_tuning *bd_tuning_read()
     const long long pad = getenv("BD_SPEC_LDS_PAD") ? num("BD_SPEC_LDS_PAD") : -1;
     t->spec_lds_pad = pad < 0 ? -1 : (pad > 140000 ? 140000 : (int)pad);
     t->spec_no_split = set("BD_SPEC_NO_SPLIT");
+    t->spec_no_quarter = set("BD_SPEC_NO_QUARTER");
     t->spec_no_granule = set("BD_SPEC_NO_GRANULE");
     t->spec_no_small_granule = set("BD_SPEC_NO_SMALL_GRANULE");
     t->spec_depth = (int)num("BD_SPEC_DEPTH");

@@ -106,6 +106,51 @@ def test_spectrum_fast_path_long_callbacks(bd, oracle, knobs, L):
         assert ref_c[0].tolist() == [0, 0, 1, 0]
 
 
+def test_spectrum_fast_path_256_sample_callbacks(bd, oracle, knobs):
+    """256-sample callbacks through the half-block kernel: two callbacks per half-block, the ring is four
+    quarter-blocks.  Streams of one callback, of an odd number (the last half-block is half a callback's), of
+    several runs with a partial last one, rows whose length is no multiple of the callback; the unpinned choices;
+    other run lengths; other sampling rates (one and no non-DC bin); the gate looks at the callback's own 256
+    samples only; the granule kernel on the same data."""
+    torch = _torch()
+    L = 256
+    for n, streams in ((L, 2), (3 * L + 5, 3), (512 * 67 + 300, 2), (L * 2 - 1, 1), (512 * 131, 2), (512 * 64 + 256, 3),
+                       (512 * 128 + 255, 1)):
+        x = _synth(bd, streams, n, first=7)
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+        if n >= L:
+            assert bd.last_kernel_name() == "bd_spectrum_band_kernel"
+    x = _synth(bd, 3, L * 300 + 9, first=21)
+    for kw in (dict(spectrum_include_dc=0), dict(spectrum_dc_packs_nyquist=1), dict(spectrum_divisor=2),
+               dict(spectrum_max_hz=50.0), dict(spectrum_max_hz=10.0)):
+        _compare(bd, oracle, "Spectrum", SR, x, L, bd.Params.default(**kw), oracle.default_params(**kw))
+    for run in ("8", "16", "32", "64", "128"):          # 128 is more than the slots hold: the launcher keeps its own
+        knobs.set("BD_SPEC_RUN", run)
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+    knobs.unset("BD_SPEC_RUN")
+    for sr in (48000, 96000):
+        y = _synth(bd, 2, 60000, first=5, sr=sr)
+        _compare(bd, oracle, "Spectrum", sr, y, L)
+        assert bd.last_kernel_name() == "bd_spectrum_band_kernel"
+    # a loud sample opens the gate of the callback it lies in and of no other (quiet stream otherwise)
+    quiet = (_synth(bd, 1, L * 12, first=3) // 64).astype(np.int16)
+    kw = dict(spectrum_threshold=10.0, min_beat_gap_ms=0)    # every callback whose gate is open is a beat
+    for cb in (4, 5, 6, 7):
+        y = quiet.copy()
+        y[0, cb * L + 100] = 20000
+        _, _, ref_c, _ = _compare(bd, oracle, "Spectrum", SR, y, L, bd.Params.default(**kw), oracle.default_params(**kw))
+        assert ref_c[0].tolist() == [1 if j == cb else 0 for j in range(12)]
+    # both kernels on the same data
+    dev = torch.from_numpy(np.ascontiguousarray(np.pad(x, ((0, 0), (0, 64 - x.shape[1] % 64))))).cuda()
+    v1, f1 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, dev, L, n_samples=x.shape[1])
+    knobs.set("BD_SPEC_NO_QUARTER", "1")
+    v2, f2 = bd.batch_candidates(bd.StrategyKind.Spectrum, SR, dev, L, n_samples=x.shape[1])
+    assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
+    knobs.unset("BD_SPEC_NO_QUARTER")
+    assert torch.equal(f1, f2)
+    assert torch.isclose(v1, v2, rtol=1e-5, atol=1.0).all()
+
+
 def test_spectrum_ragged_lengths(bd, oracle):
     # lengths that are not multiples of the callback, of a half-block run, or of 8
     for n in (511, 512, 1023, 1024, 1537, 4096 + 3, 512 * 129 + 5, 1024 * 67 + 1001):
