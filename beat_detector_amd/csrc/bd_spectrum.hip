@@ -32,6 +32,8 @@
 //   One wavefront per callback, twiddles from a 1024-entry table.
 #include "bd_internal.h"
 
+#include <type_traits>
+
 #include "bd_twiddles.inc"
 #include "bd_granule_tw.inc"
 
@@ -93,10 +95,14 @@ __device__ __forceinline__ void bd_load_hb(uint4 (&d)[4], __amdgpu_buffer_rsrc_t
 struct __attribute__((aligned(16))) bd_spec_sums { float re1, im1, re2, im2; };
 struct __attribute__((aligned(16))) bd_spec_misc { int dc, ny; float amax, pad; };
 #define BD_SPEC_SLOTS (BD_SPEC_MAX_RUN + 4)
-struct bd_spec_slots {
-    bd_spec_sums sums[BD_SPEC_SLOTS];
-    bd_spec_misc misc[BD_SPEC_SLOTS];
+template <int N> struct bd_spec_slots_t {
+    bd_spec_sums sums[N];
+    bd_spec_misc misc[N];
 };
+typedef bd_spec_slots_t<BD_SPEC_SLOTS> bd_spec_slots;
+// 128-sample callbacks: a run of 64 half-blocks and the two before it, four eighth-blocks each
+#define BD_SPEC_SLOTS_E (4 * (64 + 2))
+typedef bd_spec_slots_t<BD_SPEC_SLOTS_E> bd_spec_slots_e;
 template <int MODE> __device__ __forceinline__ int bd_spec_entry(int h)
 {
     return MODE != 1 ? h : ((h & 1) * (BD_SPEC_SLOTS / 2) + (h >> 1));
@@ -166,108 +172,151 @@ __device__ __forceinline__ void bd_spec_iter(const uint4 (&d)[4], int slot, int 
 }
 
 // all-reduce inside each half of a row (8 lanes): mirror the half, then the two quad permutations
-__device__ __forceinline__ float bd_half_row_sum(float v)
+template <int LANES> __device__ __forceinline__ float bd_sub_row_sum(float v)
 {
+    static_assert(LANES == 8, "half rows");
     v += bd_dpp_f<0x141>(v); v += bd_dpp_f<0xB1>(v); v += bd_dpp_f<0x4E>(v);
     return v;
 }
-__device__ __forceinline__ int bd_half_row_sum(int v)
+template <int LANES> __device__ __forceinline__ int bd_sub_row_sum(int v)
 {
+    static_assert(LANES == 8, "half rows");
     v += bd_dpp_i<0x141>(v); v += bd_dpp_i<0xB1>(v); v += bd_dpp_i<0x4E>(v);
     return v;
 }
-__device__ __forceinline__ float bd_half_row_max(float v)
+template <int LANES> __device__ __forceinline__ float bd_sub_row_max(float v)
 {
+    static_assert(LANES == 8, "half rows");
     v = fmaxf(v, bd_dpp_f<0x141>(v)); v = fmaxf(v, bd_dpp_f<0xB1>(v)); v = fmaxf(v, bd_dpp_f<0x4E>(v));
     return v;
 }
 
-// 256-sample callbacks (MODE 3): the ring is four quarter-blocks of 256 samples, W^{256 k} = (-i)^k, so
-//     X_k = P_k(q-3) + (-i)^k P_k(q-2) + (-1)^k P_k(q-1) + i^k P_k(q),   P_k(q) = sum_{n<256} x[256 q + n] W^{k n}.
-// One iteration is still four half-blocks, one per row of 16 lanes, but each half of a row (8 lanes)
-// owns one quarter-block: lane l8 of it loads 4 x 16 B (samples 64 c + 8 l8 + m), 128 contiguous bytes
-// per half-row and load instruction, and the sums are reduced over 8 lanes.  Half-block slot `slot`
-// parks its two quarter-blocks in entries 2 slot and 2 slot + 1.
-template <int NK, bool NYQ>
-__device__ __forceinline__ void bd_spec_iter_q(const uint4 (&d)[4], int slot, int l,
-                                               float lc1, float ls1, float lc2, float ls2, bd_spec_slots *slots)
+// Callbacks of 256 and 128 samples (MODE 3, 4): SUB = 2 or 4 callbacks per half-block.  The ring is
+// 2 SUB sub-blocks of 512 / SUB samples, and with P_k(q) = sum_n x[(512 / SUB) q + n] W^{k n}
+//     X_k = sum_{j < 2 SUB} W^{(512 / SUB) k j} P_k(q - 2 SUB + 1 + j),
+// the factors being powers of -i (256 samples) or of exp(-i pi / 4) (128 samples).
+// One iteration is still four half-blocks, one per row of 16 lanes, but each half of a row (8 lanes) owns a
+// quarter of 256 samples: lane lt of it loads 4 x 16 B (samples 64 c + 8 lt + m), 128 contiguous bytes -- a
+// line -- per half-row and load instruction, and the sums are reduced over those 8 lanes.  With 128-sample
+// callbacks the half-row takes the two eighth-blocks of its quarter one after the other (pieces c = 0, 1,
+// then 2, 3).  (Four lanes per eighth-block, 32 samples per lane and one reduction each, read 64 contiguous
+// bytes per load and were slower than the granule kernel.)  Half-block slot `slot` parks its sub-blocks in
+// entries SUB slot .. SUB slot + SUB - 1.
+template <int SUB, int NK, bool NYQ, typename SLOTS>
+__device__ __forceinline__ void bd_spec_iter_sub(const uint4 (&d)[4], int slot, int l,
+                                                 float lc1, float ls1, float lc2, float ls2, SLOTS *slots)
 {
-    float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
-    int dc = 0, ny = 0;
+    constexpr int SEQ = SUB / 2;          // sub-blocks a half-row takes one after the other
+    constexpr int PIECES = 4 / SEQ;       // 16-byte pieces of a lane per sub-block
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const unsigned w[4] = {d[c].x, d[c].y, d[c].z, d[c].w};
+    for (int h = 0; h < SEQ; h++) {
+        float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, amax = 0.f;
+        int dc = 0, ny = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int v = (int)w[q];
-            const float x0 = (float)(short)(v & 0xffff);
-            const float x1 = (float)(short)(v >> 16);
-            const int i0 = c * 8 + 2 * q, i1 = i0 + 1;
-            dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, dc, false);
-            if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, -1}, ny, false);
-            amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
-            if (NK >= 1) {
-                a1 = __builtin_fmaf(x0, BD_TWQ_C[0][i0], a1); b1 = __builtin_fmaf(x0, BD_TWQ_S[0][i0], b1);
-                a1 = __builtin_fmaf(x1, BD_TWQ_C[0][i1], a1); b1 = __builtin_fmaf(x1, BD_TWQ_S[0][i1], b1);
-            }
-            if (NK >= 2) {
-                a2 = __builtin_fmaf(x0, BD_TWQ_C[1][i0], a2); b2 = __builtin_fmaf(x0, BD_TWQ_S[1][i0], b2);
-                a2 = __builtin_fmaf(x1, BD_TWQ_C[1][i1], a2); b2 = __builtin_fmaf(x1, BD_TWQ_S[1][i1], b2);
+        for (int c = 0; c < PIECES; c++) {
+            const uint4 dv = d[h * PIECES + c];
+            const unsigned w[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int v = (int)w[q];
+                const float x0 = (float)(short)(v & 0xffff);
+                const float x1 = (float)(short)(v >> 16);
+                const int i0 = c * 8 + 2 * q, i1 = i0 + 1;
+                dc = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, 1}, dc, false);
+                if (NYQ) ny = __builtin_amdgcn_sdot2(__builtin_bit_cast(bd_short2, v), bd_short2{1, -1}, ny, false);
+                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+                if (NK >= 1) {
+                    a1 = __builtin_fmaf(x0, BD_TWQ_C[0][i0], a1); b1 = __builtin_fmaf(x0, BD_TWQ_S[0][i0], b1);
+                    a1 = __builtin_fmaf(x1, BD_TWQ_C[0][i1], a1); b1 = __builtin_fmaf(x1, BD_TWQ_S[0][i1], b1);
+                }
+                if (NK >= 2) {
+                    a2 = __builtin_fmaf(x0, BD_TWQ_C[1][i0], a2); b2 = __builtin_fmaf(x0, BD_TWQ_S[1][i0], b2);
+                    a2 = __builtin_fmaf(x1, BD_TWQ_C[1][i1], a2); b2 = __builtin_fmaf(x1, BD_TWQ_S[1][i1], b2);
+                }
             }
         }
-    }
-    bd_spec_sums r;
-    bd_spec_misc rm;
-    r.re1 = r.im1 = r.re2 = r.im2 = 0.f;
-    if (NK >= 1) {
-        r.re1 = bd_half_row_sum(a1 * lc1 - b1 * ls1);
-        r.im1 = bd_half_row_sum(a1 * ls1 + b1 * lc1);
-    }
-    if (NK >= 2) {
-        r.re2 = bd_half_row_sum(a2 * lc2 - b2 * ls2);
-        r.im2 = bd_half_row_sum(a2 * ls2 + b2 * lc2);
-    }
-    rm.dc = bd_half_row_sum(dc);
-    rm.ny = NYQ ? bd_half_row_sum(ny) : 0;
-    rm.amax = bd_half_row_max(amax);
-    rm.pad = 0.f;
-    if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1));
-    if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2));
-    if (NYQ) asm volatile("" :: "v"(rm.ny));
-    asm volatile("" :: "v"(rm.dc), "v"(rm.amax));
-    if ((l & 7) == 0 && slot >= 0) {
-        const int e = 2 * slot + (l >> 3);
-        slots->sums[e] = r;
-        slots->misc[e] = rm;
+        bd_spec_sums r;
+        bd_spec_misc rm;
+        r.re1 = r.im1 = r.re2 = r.im2 = 0.f;
+        if (NK >= 1) {
+            r.re1 = bd_sub_row_sum<8>(a1 * lc1 - b1 * ls1);
+            r.im1 = bd_sub_row_sum<8>(a1 * ls1 + b1 * lc1);
+        }
+        if (NK >= 2) {
+            r.re2 = bd_sub_row_sum<8>(a2 * lc2 - b2 * ls2);
+            r.im2 = bd_sub_row_sum<8>(a2 * ls2 + b2 * lc2);
+        }
+        rm.dc = bd_sub_row_sum<8>(dc);
+        rm.ny = NYQ ? bd_sub_row_sum<8>(ny) : 0;
+        rm.amax = bd_sub_row_max<8>(amax);
+        rm.pad = 0.f;
+        if (NK >= 1) asm volatile("" :: "v"(r.re1), "v"(r.im1));
+        if (NK >= 2) asm volatile("" :: "v"(r.re2), "v"(r.im2));
+        if (NYQ) asm volatile("" :: "v"(rm.ny));
+        asm volatile("" :: "v"(rm.dc), "v"(rm.amax));
+        if ((l & 7) == 0 && slot >= 0) {
+            const int e = SUB * slot + SEQ * (l >> 3) + h;
+            slots->sums[e] = r;
+            slots->misc[e] = rm;
+        }
     }
 }
 
-// 256-sample callback i of the run: entries i + 1 .. i + 4 are the quarter-blocks of its ring, oldest first (the
-// run's entries start at 4, after the two half-blocks before the run).  The stored pair (re, im) stands for
-// re - i im; times -i that is (-im, re).
-template <int NK, bool NYQ>
-__device__ __forceinline__ void bd_spec_finish_q(const bd_spec_args &a, const bd_spec_slots *slots, unsigned i,
-                                                 float *value_out, uint8_t *flag_out)
+// Callback i of the run: entries i + 1 .. i + 2 SUB are the sub-blocks of its ring, oldest first (the run's
+// entries start at 2 SUB, after the two half-blocks before the run).  The stored pair (re, im) stands for the
+// complex number re - i im.
+template <int SUB, int NK, bool NYQ, typename SLOTS>
+__device__ __forceinline__ void bd_spec_finish_sub(const bd_spec_args &a, const SLOTS *slots, unsigned i,
+                                                   float *value_out, uint8_t *flag_out)
 {
-    const bd_spec_sums p0 = slots->sums[i + 1], p1 = slots->sums[i + 2], p2 = slots->sums[i + 3], p3 = slots->sums[i + 4];
-    const bd_spec_misc m0 = slots->misc[i + 1], m1 = slots->misc[i + 2], m2 = slots->misc[i + 3], m3 = slots->misc[i + 4];
-    const float x_dc = (float)(m0.dc + m1.dc + m2.dc + m3.dc);
+    constexpr int R = 2 * SUB;
+    bd_spec_sums p[R];
+    int dc = 0, ny = 0;
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        p[j] = slots->sums[i + 1 + j];
+        const bd_spec_misc m = slots->misc[i + 1 + j];
+        dc += m.dc; ny += m.ny;
+    }
+    const float x_dc = (float)dc;
     float mag0 = fabsf(x_dc);
     if (NYQ) {
-        const float x_ny = (float)(m0.ny + m1.ny + m2.ny + m3.ny);
+        const float x_ny = (float)ny;
         mag0 = sqrtf(x_dc * x_dc + x_ny * x_ny);
     }
     float best = a.include_dc ? mag0 : 0.f;
+    // z = zr + i zi with zr = re, zi = -im;  (-i) z = zi - i zr
     if (NK >= 1) {
-        const float xr = (p0.re1 - p2.re1) - (p1.im1 - p3.im1), xi = (p0.im1 - p2.im1) + (p1.re1 - p3.re1);
+        float xr, xi;
+        if (SUB == 2) {       // Z0 - i Z1 - Z2 + i Z3 = (Z0 - Z2) - i (Z1 - Z3)
+            const float ar = p[0].re1 - p[2].re1, ai = -(p[0].im1 - p[2].im1);
+            const float br = p[1].re1 - p[3].re1, bi = -(p[1].im1 - p[3].im1);
+            xr = ar + bi; xi = ai - br;
+        } else {              // with D_j = Z_j - Z_{j+4} and w = exp(-i pi / 4): (D0 - i D2) + w (D1 - i D3)
+            const float d0r = p[0].re1 - p[4].re1, d0i = -(p[0].im1 - p[4].im1);
+            const float d1r = p[1].re1 - p[5].re1, d1i = -(p[1].im1 - p[5].im1);
+            const float d2r = p[2].re1 - p[6].re1, d2i = -(p[2].im1 - p[6].im1);
+            const float d3r = p[3].re1 - p[7].re1, d3i = -(p[3].im1 - p[7].im1);
+            const float ar = d0r + d2i, ai = d0i - d2r;
+            const float br = d1r + d3i, bi = d1i - d3r;
+            const float h = 0x1.6a09e6p-1f;   // sqrt(1/2): w b = ((br + bi) + i (bi - br)) sqrt(1/2)
+            xr = ar + h * (br + bi); xi = ai + h * (bi - br);
+        }
         best = fmaxf(best, sqrtf(xr * xr + xi * xi));
     }
     if (NK >= 2) {
-        const float xr = (p0.re2 + p2.re2) - (p1.re2 + p3.re2), xi = (p0.im2 + p2.im2) - (p1.im2 + p3.im2);
+        float xr, xi;
+        if (SUB == 2) {       // Z0 - Z1 + Z2 - Z3
+            xr = (p[0].re2 + p[2].re2) - (p[1].re2 + p[3].re2); xi = (p[0].im2 + p[2].im2) - (p[1].im2 + p[3].im2);
+        } else {              // sum (-i)^j Z_j = (Z0 - Z2 + Z4 - Z6) - i (Z1 - Z3 + Z5 - Z7)
+            const float ar = (p[0].re2 - p[2].re2) + (p[4].re2 - p[6].re2), ai = -((p[0].im2 - p[2].im2) + (p[4].im2 - p[6].im2));
+            const float br = (p[1].re2 - p[3].re2) + (p[5].re2 - p[7].re2), bi = -((p[1].im2 - p[3].im2) + (p[5].im2 - p[7].im2));
+            xr = ar + bi; xi = ai - br;
+        }
         best = fmaxf(best, sqrtf(xr * xr + xi * xi));
     }
     const float value = (a.divisor == 0.f) ? best : best / a.divisor;
-    const float wmax = fminf(m3.amax, 32767.f);                  // the callback's own samples (spectrum.rs:77)
+    const float wmax = fminf(slots->misc[i + R].amax, 32767.f);   // the callback's own samples (spectrum.rs:77)
     const bool gate = wmax >= (float)a.min_amp;
     *value_out = value;
     *flag_out = (gate && (value > a.threshold)) ? 1 : 0;
@@ -312,8 +361,8 @@ __device__ __forceinline__ void bd_spec_finish(const bd_spec_args &a, const bd_s
 }
 
 // MODE 0: callback length 512 (hop 512); MODE 1: callback length 1024; MODE 2: 512 m for m = 3 .. 16
-// (runs are whole callbacks: a.run_hbs is a multiple of m and of 4); MODE 3: callback length 256 (runs of
-// at most 64 half-blocks: 128 callbacks and the four quarter-blocks before them fill the LDS slots).
+// (runs are whole callbacks: a.run_hbs is a multiple of m and of 4); MODE 3 / 4: callback length 256 / 128 (runs
+// of at most 64 half-blocks: their callbacks and the sub-blocks of the two half-blocks before them fill the LDS slots).
 // NK: number of non-DC bins evaluated (0..2).  NYQ: bin 0 carries the Nyquist sum.
 // DEPTH: register buffers of one iteration (4 KB per wavefront) each; loads run DEPTH - 1 iterations ahead.
 template <int MODE, int NK, bool NYQ, int DEPTH>
@@ -340,22 +389,25 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // block walk four consecutive runs, so three of them find that half-block's sums in their
     // neighbour's LDS slots once the block has met at a barrier; only a block's first wavefront (and a
     // stream's first run after another stream's last) reads the half-block again.
-    // 256-sample callbacks: the first callbacks of a run need the three quarter-blocks before it, i.e. the
-    // two half-blocks before the run (read again by every run but a stream's first).
+    // 256- and 128-sample callbacks: the first callbacks of a run need the three quarter-blocks (seven eighth-
+    // blocks) before it, i.e. the two half-blocks before the run (read again by every run but a stream's first).
     const bool from_neighbour = MODE == 0 && wave > 0 && r > 0;
-    const bool reread = (MODE == 0 && hb0 > 0 && !from_neighbour) || (MODE == 3 && hb0 > 0);
+    constexpr int SUB = MODE == 3 ? 2 : MODE == 4 ? 4 : 1;     // callbacks per half-block
+    constexpr int SUB_LANES = SUB > 1 ? 8 : 16;               // lanes that share a reduction
+    const bool reread = (MODE == 0 && hb0 > 0 && !from_neighbour) || (SUB > 1 && hb0 > 0);
     const int it_begin = reread ? -1 : 0;
-    const int64_t hb_lo = reread ? hb0 - (MODE == 3 ? 2 : 1) : hb0;   // first half-block the run reads
+    const int64_t hb_lo = reread ? hb0 - (SUB > 1 ? 2 : 1) : hb0;   // first half-block the run reads
 
-    const int lt = MODE == 3 ? (l & 7) : l;                  // position of the lane's samples: 8 lt + m
+    const int lt = l & (SUB_LANES - 1);                      // position of the lane's samples: 8 lt + m
     const float lc1 = BD_LANE_C[0][lt], ls1 = BD_LANE_S[0][lt];
     const float lc2 = BD_LANE_C[1][lt], ls2 = BD_LANE_S[1][lt];
 
     // slot 0 of a hop-512 run is the half-block before the run; the others follow
-    __shared__ bd_spec_slots lds_slots[4];
-    bd_spec_slots *slots = &lds_slots[wave];
-    constexpr int SLOT0 = MODE == 0 ? 1 : (MODE == 3 ? 2 : 0);
-    if (MODE == 3 && hb0 == 0 && lane < 4) {
+    typedef typename std::conditional<MODE == 4, bd_spec_slots_e, bd_spec_slots>::type slots_t;
+    __shared__ slots_t lds_slots[4];
+    slots_t *slots = &lds_slots[wave];
+    constexpr int SLOT0 = MODE == 0 ? 1 : (SUB > 1 ? 2 : 0);
+    if (SUB > 1 && hb0 == 0 && lane < 2 * SUB) {
         bd_spec_sums z;
         bd_spec_misc zm;
         z.re1 = z.im1 = z.re2 = z.im2 = zm.amax = zm.pad = 0.f;
@@ -376,19 +428,19 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // DEPTH register buffers in a ring, each filled DEPTH - 1 iterations ahead of its use.  Rows whose
     // loads were dropped produce sums of zeros that no stored result uses.
     const int64_t hb_end = n_hb < hb0 + (int64_t)a.run_hbs ? n_hb : hb0 + (int64_t)a.run_hbs;
-    // (256-sample callbacks: the stream's last half-block may be half a callback's; the descriptor ends with the callbacks)
+    // (256- and 128-sample callbacks: the callbacks may end inside the stream's last half-block; the descriptor ends with them)
     int64_t s_end = hb_end * BD_HALF_BLOCK;
-    if (MODE == 3 && (int64_t)a.n_cb * 256 < s_end) s_end = (int64_t)a.n_cb * 256;
+    if (SUB > 1 && (int64_t)a.n_cb * (BD_HALF_BLOCK / SUB) < s_end) s_end = (int64_t)a.n_cb * (BD_HALF_BLOCK / SUB);
     const __amdgpu_buffer_rsrc_t rs = bd_uniform_rsrc(sp + hb_lo * BD_HALF_BLOCK, (unsigned)((s_end - hb_lo * BD_HALF_BLOCK) * 2));
     // byte offset of this lane's first piece in iteration 0, counted from half-block hb_lo (negative,
     // i.e. out of range as an unsigned offset, for the rows of iteration -1 before it)
-    const int lane_off = (int)(hb0 - hb_lo + g) * (BD_HALF_BLOCK * 2) + (MODE == 3 ? 512 * (l >> 3) + 16 * (l & 7) : 16 * l);
+    const int lane_off = (int)(hb0 - hb_lo + g) * (BD_HALF_BLOCK * 2) + (SUB > 1 ? 512 * (l >> 3) : 0) + 16 * lt;
     uint4 R[DEPTH][4];
     auto load = [&](uint4 (&d)[4], int it) {
-        bd_load_hb<MODE == 3 ? 128u : 256u>(d, rs, (unsigned)(lane_off + it * (4 * BD_HALF_BLOCK * 2)));
+        bd_load_hb<16u * SUB_LANES>(d, rs, (unsigned)(lane_off + it * (4 * BD_HALF_BLOCK * 2)));
     };
     auto run = [&](const uint4 (&d)[4], int it) {
-        if constexpr (MODE == 3) bd_spec_iter_q<NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
+        if constexpr (SUB > 1) bd_spec_iter_sub<SUB, NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
         else bd_spec_iter<MODE, NK, NYQ>(d, 4 * it + g + SLOT0, l, lc1, ls1, lc2, ls2, slots);
     };
     {
@@ -424,9 +476,9 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    const uint64_t cb0 = MODE == 2 ? (uint64_t)hb0 / a.hb_per_cb : MODE == 3 ? (uint64_t)hb0 * 2 : (uint64_t)(hb0 >> MODE);
+    const uint64_t cb0 = MODE == 2 ? (uint64_t)hb0 / a.hb_per_cb : SUB > 1 ? (uint64_t)hb0 * SUB : (uint64_t)(hb0 >> MODE);
     const uint64_t cb_left = a.n_cb - cb0;
-    const unsigned n_res_run = MODE == 2 ? (unsigned)(n_it * 4) / a.hb_per_cb : (unsigned)(n_it * (MODE == 3 ? 8 : MODE == 0 ? 4 : 2));
+    const unsigned n_res_run = MODE == 2 ? (unsigned)(n_it * 4) / a.hb_per_cb : (unsigned)(n_it * (SUB > 1 ? 4 * SUB : MODE == 0 ? 4 : 2));
     const unsigned n_res = cb_left < n_res_run ? (unsigned)cb_left : n_res_run; // buffer stores past it are dropped
     const uint64_t o0 = s * a.out_stride + cb0;
     __amdgpu_buffer_rsrc_t rf = bd_out_rsrc(a.flags + o0, n_res);
@@ -439,7 +491,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
         rv = bd_out_rsrc(a.values + (o0 & 0x3ffffull & ~127ull), n_res * 4u);
     for (unsigned i = lane; i < n_res_run; i += 64) {
         float value; uint8_t flag;
-        if constexpr (MODE == 3) bd_spec_finish_q<NK, NYQ>(a, slots, i, &value, &flag);
+        if constexpr (SUB > 1) bd_spec_finish_sub<SUB, NK, NYQ>(a, slots, i, &value, &flag);
         else bd_spec_finish<MODE, NK, NYQ>(a, slots, i, &value, &flag);
         bd_store_stream_u8(rf, i, flag);
         const unsigned vb = __builtin_bit_cast(unsigned, value);
@@ -456,7 +508,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
 #else
     for (unsigned i = lane; i < n_res_run; i += 64) {
         float value; uint8_t flag;
-        if constexpr (MODE == 3) bd_spec_finish_q<NK, NYQ>(a, slots, i, &value, &flag);
+        if constexpr (SUB > 1) bd_spec_finish_sub<SUB, NK, NYQ>(a, slots, i, &value, &flag);
         else bd_spec_finish<MODE, NK, NYQ>(a, slots, i, &value, &flag);
         bd_store_stream_u8(rf, i, flag);
         bd_store_stream_f32(rv, i * 4u, value);   // a zero-sized descriptor drops the store
@@ -799,8 +851,9 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
     // 512 and 1024 samples, and the longer multiples of 512 up to 8192 (2048, 4096, ...: the ring is the
     // callback's last two half-blocks)
     const uint32_t hb_per_cb = callback_len / BD_HALF_BLOCK;
-    // (and 256 samples: two callbacks per half-block; BD_SPEC_NO_QUARTER=1 leaves them to the granule kernel)
-    const bool quarter = callback_len == 256;
+    // (and 256 / 128 samples: two / four callbacks per half-block; BD_SPEC_NO_QUARTER=1 leaves them to the granule kernel)
+    const bool quarter = callback_len == 256 || callback_len == 128;
+    const uint32_t cb_per_hb = quarter ? BD_HALF_BLOCK / callback_len : 1;
     const bool fast_len = (callback_len % BD_HALF_BLOCK == 0 && hb_per_cb >= 1 && hb_per_cb <= 16) ||
                           (quarter && !bd_tuning_get().spec_no_quarter);
     const bool fast_bins = plan.last_bin <= 2;
@@ -810,7 +863,7 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         bd_spec_args a;
         a.samples = samples; a.values = values; a.flags = flags;
         a.stride = stride; a.n_cb = n_cb; a.out_stride = out_stride;
-        const uint64_t n_hb = quarter ? (n_cb + 1) / 2 : n_cb * (callback_len / BD_HALF_BLOCK);
+        const uint64_t n_hb = quarter ? (n_cb + cb_per_hb - 1) / cb_per_hb : n_cb * (callback_len / BD_HALF_BLOCK);
         if (n_hb > 0xffffffffull) { bd_set_error("stream too long for the fast Spectrum kernel"); return BD_ERR_UNSUPPORTED; }
         a.n_hb = (uint32_t)n_hb;
         // run length: long runs amortise the one re-read half-block at each run
@@ -844,10 +897,16 @@ int bd_launch_spectrum(const bd_plan &plan, const int16_t *samples, uint64_t n_s
         const int depth = tune.spec_depth ? tune.spec_depth : 2;
         const int nk = plan.last_bin; // bins 1..last_bin
         const bool nyq = plan.dc_packs_nyquist && plan.first_bin == 0;
-        if (quarter) {
+        if (callback_len == 256) {
             if (nk == 0) launch_fast<3, 0>(nyq, depth, a, grid, lds_pad, st);
             else if (nk == 1) launch_fast<3, 1>(nyq, depth, a, grid, lds_pad, st);
             else launch_fast<3, 2>(nyq, depth, a, grid, lds_pad, st);
+        } else if (callback_len == 128) {
+            // (the slots of 128-sample callbacks take 4 x 4 KB more static LDS per workgroup: the same two workgroups per CU)
+            const unsigned pad_e = lds_pad > 17000u && tune.spec_lds_pad < 0 ? lds_pad - 17000u : lds_pad;
+            if (nk == 0) launch_fast<4, 0>(nyq, depth, a, grid, pad_e, st);
+            else if (nk == 1) launch_fast<4, 1>(nyq, depth, a, grid, pad_e, st);
+            else launch_fast<4, 2>(nyq, depth, a, grid, pad_e, st);
         } else if (callback_len == 512) {
             if (nk == 0) launch_fast<0, 0>(nyq, depth, a, grid, lds_pad, st);
             else if (nk == 1) launch_fast<0, 1>(nyq, depth, a, grid, lds_pad, st);

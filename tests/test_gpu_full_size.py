@@ -126,7 +126,9 @@ def test_extension_batches(bd, oracle_ext):
     ("Spectrum", 441, SR, "bd_spectrum_split_kernel"), ("Spectrum", 819, SR, "bd_spectrum_g63_kernel"), ("Spectrum", 450, SR, "bd_spectrum_split_kernel"), ("Spectrum", 529, SR, "bd_spectrum_split_kernel"),
     ("Spectrum", 700, SR, "bd_spectrum_split_kernel"), ("Spectrum", 900, SR, "bd_spectrum_window_kernel"), ("Spectrum", 480, SR, "bd_spectrum_split_kernel"), ("Spectrum", 96, SR, "bd_spectrum_granule_kernel"),
     ("Spectrum", 512, 16000, "bd_spectrum_granule_kernel"), ("Spectrum", 441, 22050, "bd_spectrum_window_kernel"),
-    ("LPF", 441, SR, "bd_lpf_lines_kernel"), ("LPF", 1000, SR, "bd_lpf_lines_kernel")])
+    ("Spectrum", 256, SR, "bd_spectrum_band_kernel"), ("Spectrum", 128, SR, "bd_spectrum_band_kernel"),
+    ("LPF", 441, SR, "bd_lpf_lines_kernel"), ("LPF", 1000, SR, "bd_lpf_lines_kernel"), ("LPF", 200, SR, "bd_lpf_lines_kernel"),
+    ("LPF", 32, SR, "bd_lpf_window_kernel")])
 def test_other_lengths_and_rates_at_4096_streams(bd, oracle, kind_name, L, sr, kernel):
     """The kernels behind callback lengths off the 64-sample grid and behind low sampling rates, on a
     batch large enough to fill the GPU many times over; sampled streams against the oracle."""

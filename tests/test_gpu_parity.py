@@ -106,16 +106,16 @@ def test_spectrum_fast_path_long_callbacks(bd, oracle, knobs, L):
         assert ref_c[0].tolist() == [0, 0, 1, 0]
 
 
-def test_spectrum_fast_path_256_sample_callbacks(bd, oracle, knobs):
-    """256-sample callbacks through the half-block kernel: two callbacks per half-block, the ring is four
-    quarter-blocks.  Streams of one callback, of an odd number (the last half-block is half a callback's), of
+@pytest.mark.parametrize("L", [256, 128])
+def test_spectrum_fast_path_256_and_128_sample_callbacks(bd, oracle, knobs, L):
+    """256- and 128-sample callbacks through the half-block kernel: two / four callbacks per half-block, the ring
+    is four quarter-blocks / eight eighth-blocks.  Streams of one callback, of an odd number (the last half-block is half a callback's), of
     several runs with a partial last one, rows whose length is no multiple of the callback; the unpinned choices;
-    other run lengths; other sampling rates (one and no non-DC bin); the gate looks at the callback's own 256
-    samples only; the granule kernel on the same data."""
+    other run lengths; other sampling rates (one and no non-DC bin); the gate looks at the callback's own samples
+    only; the granule kernel on the same data."""
     torch = _torch()
-    L = 256
     for n, streams in ((L, 2), (3 * L + 5, 3), (512 * 67 + 300, 2), (L * 2 - 1, 1), (512 * 131, 2), (512 * 64 + 256, 3),
-                       (512 * 128 + 255, 1)):
+                       (512 * 128 + 255, 1), (512 * 64 + 128, 1), (512 * 65 + 384 + 17, 2), (5 * L, 1), (7 * L + 3, 1)):
         x = _synth(bd, streams, n, first=7)
         _compare(bd, oracle, "Spectrum", SR, x, L)
         if n >= L:
