@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t task = bd_block_index() * 4 + wave;
     if (task >= a.n_tasks) {
-        if (MODE == 0) __syncthreads();    // the block's other wavefronts meet at one barrier (below)
+        if (MODE == 0 || MODE >= 3) __syncthreads();    // the block's other wavefronts meet at one barrier (below)
         return;
     }
     const uint64_t s = task / a.runs_per_stream;
@@ -390,11 +390,12 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // neighbour's LDS slots once the block has met at a barrier; only a block's first wavefront (and a
     // stream's first run after another stream's last) reads the half-block again.
     // 256- and 128-sample callbacks: the first callbacks of a run need the three quarter-blocks (seven eighth-
-    // blocks) before it, i.e. the two half-blocks before the run (read again by every run but a stream's first).
-    const bool from_neighbour = MODE == 0 && wave > 0 && r > 0;
+    // blocks) before it, i.e. the two half-blocks before the run: from the neighbour's slots like the one
+    // half-block of hop 512, or read again.
     constexpr int SUB = MODE == 3 ? 2 : MODE == 4 ? 4 : 1;     // callbacks per half-block
     constexpr int SUB_LANES = SUB > 1 ? 8 : 16;               // lanes that share a reduction
-    const bool reread = (MODE == 0 && hb0 > 0 && !from_neighbour) || (SUB > 1 && hb0 > 0);
+    const bool from_neighbour = (MODE == 0 || SUB > 1) && wave > 0 && r > 0;
+    const bool reread = (MODE == 0 || SUB > 1) && hb0 > 0 && !from_neighbour;
     const int it_begin = reread ? -1 : 0;
     const int64_t hb_lo = reread ? hb0 - (SUB > 1 ? 2 : 1) : hb0;   // first half-block the run reads
 
@@ -465,13 +466,19 @@ __global__ __launch_bounds__(256) void bd_spectrum_band_kernel(bd_spec_args a)
     // results of the run: consecutive lanes finish and store consecutive callbacks
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (MODE == 0) {
+    if (MODE == 0 || SUB > 1) {
         __syncthreads();                       // every wavefront of the block has parked its sums
-        if (from_neighbour && lane == 0) {
+        if (MODE == 0 && from_neighbour && lane == 0) {
             // the last half-block of the run before this one (a whole run: this is not its stream's first)
             const int e = bd_spec_entry<MODE>((int)a.run_hbs);
             slots->sums[0] = lds_slots[wave - 1].sums[e];
             slots->misc[0] = lds_slots[wave - 1].misc[e];
+        }
+        if (SUB > 1 && from_neighbour && lane < 2 * SUB) {
+            // the sub-blocks of the last two half-blocks of the run before this one: its last 2 SUB entries
+            const int e = SUB * (int)a.run_hbs + lane;
+            slots->sums[lane] = lds_slots[wave - 1].sums[e];
+            slots->misc[lane] = lds_slots[wave - 1].misc[e];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
