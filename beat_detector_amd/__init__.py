@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     analyze_batch,
     analyze_batch_host,
     analyze_batch_multi,
+    analyze_batch_devices,
     analyze_batch_noalloc,
     NOALLOC_MAX_CALLBACKS,
     analyze_batch_ragged,

@@ -187,6 +187,8 @@ def lib() -> C.CDLL:
         "bd_batch_candidates": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, u64, vp]),
         "bd_analyze_batch_host": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, i32]),
         "bd_analyze_batch_multi": (i32, [i32, u32, pp, vp, u64, u64, u64, u32, vp, vp, vp, vp, vp, u32, C.POINTER(i32), i32]),
+        "bd_analyze_batch_devices": (i32, [i32, u32, pp, C.POINTER(vp), C.POINTER(u64), u64, u64, u32, C.POINTER(vp), C.POINTER(vp),
+                                           u64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u32, C.POINTER(i32), i32]),
         "bd_refractory": (i32, [u32, pp, u32, vp, u64, u64, u64, vp, vp, vp, u32, vp]),
         "bd_u16_data_to_i16": (i32, [vp, vp, u64, vp]),
         "bd_f32_data_to_i16": (i32, [vp, vp, u64, vp]),
@@ -235,7 +237,7 @@ EXPORTED_SYMBOLS = (
     "bd_kind_description bd_kind_min_duration_between_beats_ms bd_detector_create "
     "bd_detector_is_beat bd_detector_kind bd_detector_last bd_detector_destroy bd_batch_callbacks "
     "bd_batch_max_beats bd_analyze_batch bd_analyze_batch_noalloc bd_analyze_batch_ragged bd_batch_candidates bd_analyze_batch_host "
-    "bd_analyze_batch_multi bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
+    "bd_analyze_batch_multi bd_analyze_batch_devices bd_refractory bd_u16_data_to_i16 bd_f32_data_to_i16 bd_stereo_to_mono bd_synth_fill "
     "bd_synth_fill_host bd_last_kernel_name bd_tuning_reload bd_live_create bd_live_set_on_beat bd_live_submit bd_live_submit_ragged bd_live_poll "
     "bd_live_destroy bd_start_listening bd_listener_join bd_onset_default_params bd_onset_frames "
     "bd_onset_stft bd_onset_pick bd_onset_batch bd_biquad_default_params bd_biquad_design_lowpass bd_biquad_envelope bd_probe_read bd_probe_read_ex "
@@ -513,6 +515,47 @@ def analyze_batch(kind: StrategyKind, sampling_rate: int, samples, callback_len:
                                       _row_stride(out.flags, out.values), out.beat_count.data_ptr(), out.beat_idx.data_ptr(), out.beat_ms.data_ptr(),
                                       out.beat_idx.shape[1], _stream_ptr(stream)))
     return out
+
+
+def analyze_batch_devices(kind: StrategyKind, sampling_rate: int, shards, callback_len: int,
+                          n_samples: Optional[int] = None, params: Optional[Params] = None,
+                          max_beats: Optional[int] = None, want_values: bool = True) -> List[BatchResult]:
+    """bd_analyze_batch_devices: `shards` is a list of CUDA int16 tensors [n_streams_g, stride] (the same stride),
+    each resident on the GPU that is to analyse it; one host thread per shard inside the library, no inter-GPU
+    traffic.  Returns one BatchResult per shard, on the shard's device; the call has finished when it returns."""
+    if not shards:
+        return []
+    for t in shards:
+        _require_cuda(t, torch.int16, "shard")
+    stride = shards[0].shape[1]
+    if any(t.shape[1] != stride for t in shards):
+        raise BeatDetectorError(BD_ERR_INVALID_ARG, "all shards must have the same row stride")
+    n = stride if n_samples is None else n_samples
+    n_cb = n // callback_len if callback_len else 0
+    if max_beats is None:
+        max_beats = max(1, batch_max_beats(kind, sampling_rate, n, callback_len, params)) if callback_len else 1
+    outs = []
+    for t in shards:
+        dev, rows = t.device, t.shape[0]
+        outs.append(BatchResult(
+            _out_rows(rows, n_cb, torch.float32, dev) if want_values else None,
+            _out_rows(rows, n_cb, torch.uint8, dev),
+            torch.zeros((rows,), dtype=torch.int32, device=dev),
+            torch.zeros((rows, max_beats), dtype=torch.int32, device=dev),
+            torch.zeros((rows, max_beats), dtype=torch.int32, device=dev)))
+    for t in shards:
+        torch.cuda.synchronize(t.device)            # the library's streams do not wait for torch's
+    g = len(shards)
+    arr = lambda ptrs: (C.c_void_p * g)(*ptrs)
+    out_stride = _row_stride(outs[0].flags, outs[0].values)
+    _check(lib().bd_analyze_batch_devices(
+        kind.value, sampling_rate, _pp(params), arr([t.data_ptr() for t in shards]),
+        (C.c_uint64 * g)(*[t.shape[0] for t in shards]), n, stride, callback_len,
+        arr([o.values.data_ptr() for o in outs]) if want_values else None, arr([o.flags.data_ptr() for o in outs]), out_stride,
+        arr([o.beat_count.data_ptr() for o in outs]), arr([o.beat_idx.data_ptr() for o in outs]),
+        arr([o.beat_ms.data_ptr() for o in outs]), max_beats,
+        (C.c_int * g)(*[t.device.index if t.device.index is not None else torch.cuda.current_device() for t in shards]), g))
+    return outs
 
 
 NOALLOC_MAX_CALLBACKS = 96 << 20  # BD_NOALLOC_SCRATCH_BYTES of include/beat_detector_hip.h

@@ -588,3 +588,68 @@ extern "C" int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd
         }
     return BD_OK;
 }
+
+extern "C" int bd_analyze_batch_devices(int kind, uint32_t sampling_rate, const bd_params *params,
+                                        const int16_t **samples, const uint64_t *n_streams, uint64_t n_samples,
+                                        uint64_t stream_stride, uint32_t callback_len,
+                                        float **values, uint8_t **flags, uint64_t out_stride,
+                                        uint32_t **beat_count, uint32_t **beat_idx, uint32_t **beat_ms,
+                                        uint32_t max_beats, const int *devices, int n_devices)
+{
+    if (!devices || n_devices <= 0) { bd_set_error("bd_analyze_batch_devices: empty device list"); return BD_ERR_INVALID_ARG; }
+    if (!samples || !n_streams || !flags || !beat_count) {
+        bd_set_error("bd_analyze_batch_devices: samples, n_streams, flags and beat_count must not be NULL");
+        return BD_ERR_INVALID_ARG;
+    }
+    // argument errors are reported once, here, before any worker starts
+    {
+        bd_plan plan;
+        int s = bd_make_plan(kind, sampling_rate, params, &plan);
+        if (s != BD_OK) return s;
+        if (callback_len == 0) { bd_set_error("callback_len must be >= 1"); return BD_ERR_EMPTY_WINDOW; }
+        if (stream_stride < n_samples) { bd_set_error("stream_stride < n_samples"); return BD_ERR_INVALID_ARG; }
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            bd_set_error("no HIP device available (this library has no CPU path)");
+            return BD_ERR_NO_DEVICE;
+        }
+        for (int g = 0; g < n_devices; g++) {
+            if (devices[g] < 0 || devices[g] >= count) {
+                bd_set_error("device %d out of range (%d devices)", devices[g], count);
+                return BD_ERR_INVALID_ARG;
+            }
+            if (n_streams[g] > 0 && (!samples[g] || !flags[g] || !beat_count[g])) {
+                bd_set_error("shard %d: samples, flags and beat_count must not be NULL", g);
+                return BD_ERR_INVALID_ARG;
+            }
+        }
+    }
+    std::vector<int> status((size_t)n_devices, BD_OK);
+    std::vector<std::string> messages((size_t)n_devices);
+    std::vector<std::thread> workers;
+    for (int g = 0; g < n_devices; g++) {
+        if (n_streams[g] == 0) continue;
+        workers.emplace_back([=, &status, &messages] {
+            auto fail = [&](int st) { status[(size_t)g] = st; messages[(size_t)g] = bd_last_error(); };
+            int st = bd_check_hip(hipSetDevice(devices[g]), "hipSetDevice");
+            if (st != BD_OK) { fail(st); return; }
+            hipStream_t stream = nullptr;
+            st = bd_check_hip(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+            if (st != BD_OK) { fail(st); return; }
+            st = bd_analyze_batch(kind, sampling_rate, params, samples[g], n_streams[g], n_samples, stream_stride,
+                                  callback_len, values ? values[g] : nullptr, flags[g], out_stride, beat_count[g],
+                                  beat_idx ? beat_idx[g] : nullptr, beat_ms ? beat_ms[g] : nullptr, max_beats, stream);
+            if (st != BD_OK) fail(st);
+            const int sync = bd_check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if (st == BD_OK && sync != BD_OK) fail(sync);
+            (void)hipStreamDestroy(stream);
+        });
+    }
+    for (auto &w : workers) w.join();
+    for (int g = 0; g < n_devices; g++)
+        if (status[(size_t)g] != BD_OK) {
+            bd_set_error("shard %d on device %d: %s", g, devices[g], messages[(size_t)g].c_str());
+            return status[(size_t)g];
+        }
+    return BD_OK;
+}

@@ -164,6 +164,7 @@ extern "C" {
     pub fn bd_batch_candidates(kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64, n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8, out_stride: u64, hip_stream: *mut c_void) -> c_int;
     pub fn bd_analyze_batch_host(kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64, n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, device: c_int) -> c_int;
     pub fn bd_analyze_batch_multi(kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64, n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut f32, flags: *mut u8, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, devices: *const c_int, n_devices: c_int) -> c_int;
+    pub fn bd_analyze_batch_devices(kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *mut *const i16, n_streams: *const u64, n_samples: u64, stream_stride: u64, callback_len: u32, values: *mut *mut f32, flags: *mut *mut u8, out_stride: u64, beat_count: *mut *mut u32, beat_idx: *mut *mut u32, beat_ms: *mut *mut u32, max_beats: u32, devices: *const c_int, n_devices: c_int) -> c_int;
     pub fn bd_refractory(sampling_rate: u32, params: *const bd_params, callback_len: u32, flags: *const u8, flags_stride: u64, n_streams: u64, n_callbacks: u64, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, hip_stream: *mut c_void) -> c_int;
     pub fn bd_analyze_batch_noalloc(kind: c_int, sampling_rate: u32, params: *const bd_params, samples: *const i16, n_streams: u64, n_samples: u64, stream_stride: u64, callback_len: u32, beat_count: *mut u32, beat_idx: *mut u32, beat_ms: *mut u32, max_beats: u32, hip_stream: *mut c_void) -> c_int;
 

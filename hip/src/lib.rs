@@ -386,10 +386,72 @@ pub unsafe fn analyze_batch_on(
     Ok(())
 }
 
+/// One resident shard of a batch on one GPU: device pointers of `device`, as in [`analyze_batch_on`].
+#[derive(Debug, Clone, Copy)]
+pub struct DeviceShard {
+    pub device: i32,
+    pub samples: *const i16,
+    pub n_streams: u64,
+    pub flags: *mut u8,
+    pub beat_count: *mut u32,
+    pub beat_idx: *mut u32,
+    pub beat_ms: *mut u32,
+}
+
+/// Every shard on its own GPU at once, from one call: the library starts one host thread per shard,
+/// each selects its device, enqueues the batch on a stream of its own and waits for it.  Samples stay
+/// where they are (no copy, no traffic between GPUs); the call returns when all shards have finished.
+/// This is the multi-GPU entry for samples that are already resident; [`analyze_batch_multi`] is the
+/// one for host slices.
+///
+/// # Safety
+/// Every pointer of every shard must be a device pointer of that shard's `device` with the extents of
+/// [`analyze_batch_on`], valid until the call returns.
+pub unsafe fn analyze_batch_devices(
+    kind: StrategyKind,
+    sampling_rate: u32,
+    shards: &[DeviceShard],
+    n_samples: u64,
+    stream_stride: u64,
+    callback_len: u32,
+    max_beats: u32,
+) -> Result<(), String> {
+    let mut samples: Vec<*const i16> = shards.iter().map(|s| s.samples).collect();
+    let n_streams: Vec<u64> = shards.iter().map(|s| s.n_streams).collect();
+    let mut flags: Vec<*mut u8> = shards.iter().map(|s| s.flags).collect();
+    let mut count: Vec<*mut u32> = shards.iter().map(|s| s.beat_count).collect();
+    let mut idx: Vec<*mut u32> = shards.iter().map(|s| s.beat_idx).collect();
+    let mut ms: Vec<*mut u32> = shards.iter().map(|s| s.beat_ms).collect();
+    let devices: Vec<c_int> = shards.iter().map(|s| s.device as c_int).collect();
+    let rc = ffi::bd_analyze_batch_devices(
+        kind.as_raw(),
+        sampling_rate,
+        std::ptr::null(),
+        samples.as_mut_ptr(),
+        n_streams.as_ptr(),
+        n_samples,
+        stream_stride,
+        callback_len,
+        std::ptr::null_mut(),
+        flags.as_mut_ptr(),
+        0,
+        count.as_mut_ptr(),
+        idx.as_mut_ptr(),
+        ms.as_mut_ptr(),
+        max_beats,
+        devices.as_ptr(),
+        devices.len() as c_int,
+    );
+    if rc != ffi::BD_OK {
+        return Err(last_error());
+    }
+    Ok(())
+}
+
 /// The host-slice entry sharded by stream over several GPUs of the node (contiguous shards, no
 /// traffic between GPUs).  Like [`analyze_batch`] it copies the samples over PCIe, which bounds
-/// it at about 30 GB/s per GPU; with samples already on the GPUs use [`analyze_batch_on`] per
-/// device instead.
+/// it at about 30 GB/s per GPU; with samples already on the GPUs use [`analyze_batch_devices`] (or
+/// [`analyze_batch_on`] from a thread or process per device) instead.
 pub fn analyze_batch_multi(kind: StrategyKind, sampling_rate: u32, samples: &[i16], n_samples: usize, callback_len: u32, devices: &[i32]) -> Result<BeatLists, String> {
     if n_samples == 0 || samples.len() % n_samples != 0 {
         return Err("samples.len() must be a multiple of n_samples".to_string());

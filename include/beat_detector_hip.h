@@ -191,6 +191,24 @@ int bd_analyze_batch_multi(int kind, uint32_t sampling_rate, const bd_params *pa
                            uint32_t *beat_count, uint32_t *beat_idx, uint32_t *beat_ms,
                            uint32_t max_beats, const int *devices, int n_devices);
 
+/* The same sharding for samples that already live on the GPUs: shard g is a
+ * batch of n_streams[g] streams resident on devices[g], and samples[g] /
+ * values[g] / flags[g] / beat_count[g] / beat_idx[g] / beat_ms[g] are device
+ * pointers there, with the meaning and the NULL rules of bd_analyze_batch
+ * (the arrays themselves are host memory; `values`, `beat_idx`, `beat_ms`
+ * may be NULL as a whole).  One host thread per shard selects its device,
+ * enqueues the batch on a stream of its own and waits for it; the call
+ * returns when every shard has finished.  No inter-GPU traffic: streams are
+ * independent (src/strategies/mod.rs:39-56, spectrum.rs:38-44).  A device may
+ * be listed more than once (its shards then run one after the other or
+ * concurrently, as the device schedules them). */
+int bd_analyze_batch_devices(int kind, uint32_t sampling_rate, const bd_params *params,
+                             const int16_t **samples, const uint64_t *n_streams, uint64_t n_samples,
+                             uint64_t stream_stride, uint32_t callback_len,
+                             float **values, uint8_t **flags, uint64_t out_stride,
+                             uint32_t **beat_count, uint32_t **beat_idx, uint32_t **beat_ms,
+                             uint32_t max_beats, const int *devices, int n_devices);
+
 /* The refractory rule alone (Strategy::last_beat_beyond_threshold,
  * src/lib.rs:115-127, with the clock of src/strategies/mod.rs:76-84) applied
  * to per-callback decisions already on the device (rows of flags_stride

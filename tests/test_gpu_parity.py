@@ -732,6 +732,36 @@ def test_host_pointer_entry_points(bd, oracle):
                 assert res.beats(s) == ref_b[s]
 
 
+def test_resident_shards_on_listed_devices(bd, oracle):
+    """bd_analyze_batch_devices: shards that already live on their GPU, one host thread each inside the library.
+    (One GPU here: it is listed for every shard.)  Shards of different sizes, an empty one, both strategies, a
+    callback length off the grid; every shard equals the same streams analysed in one batch and the oracle."""
+    torch = _torch()
+    x = _synth(bd, 11, SR * 3 + 77, first=30)
+    n = x.shape[1]
+    dev = torch.zeros((11, (n + 63) & ~63), dtype=torch.int16, device="cuda")
+    dev[:, :n] = torch.from_numpy(x).cuda()
+    cuts = [0, 4, 4, 9, 11]                                  # shards of 4, 0, 5 and 2 streams
+    shards = [dev[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    for kind_name, L in (("Spectrum", 512), ("LPF", 1024), ("Spectrum", 529), ("LPF", 441)):
+        kind = bd.StrategyKind[kind_name]
+        okind = oracle.KIND_SPECTRUM if kind_name == "Spectrum" else oracle.KIND_LPF
+        _, ref_c, ref_b = util.oracle_batch(oracle, okind, SR, x, L)
+        whole = bd.analyze_batch(kind, SR, dev, L, n_samples=n)
+        outs = bd.analyze_batch_devices(kind, SR, shards, L, n_samples=n)
+        assert len(outs) == 4 and outs[1].flags.shape[0] == 0
+        for (a, b), res in zip(zip(cuts[:-1], cuts[1:]), outs):
+            np.testing.assert_array_equal(res.flags.cpu().numpy(), ref_c[a:b])
+            assert torch.equal(res.values, whole.values[a:b]) and torch.equal(res.beat_count, whole.beat_count[a:b])
+            for s in range(b - a):
+                assert res.beats(s) == ref_b[a + s]
+        no_values = bd.analyze_batch_devices(kind, SR, shards, L, n_samples=n, want_values=False)
+        assert all(r.values is None for r in no_values)
+        assert all(torch.equal(r.flags, o.flags) and torch.equal(r.beat_idx, o.beat_idx) for r, o in zip(no_values, outs))
+    with pytest.raises(bd.BeatDetectorError):
+        bd.analyze_batch_devices(bd.StrategyKind.LPF, SR, [dev[:2], dev[2:5, :1024]], 1024)   # strides differ
+
+
 def test_host_entry_in_many_chunks(bd, oracle, knobs):
     """The host-pointer entry with chunks of 3 streams (two slots reused many times), all outputs requested."""
     n = SR * 2 + 100

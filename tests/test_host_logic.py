@@ -114,3 +114,32 @@ def test_multi_device_entry_validates_before_it_starts_workers(bd):
     assert L.bd_analyze_batch_multi(7, 44100, None, vp(x), 2, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, dev, 2) == -1
     assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 2, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, None, 0) == -1
     assert L.bd_analyze_batch_multi(1, 44100, None, vp(x), 0, 2048, 2048, 512, None, None, vp(cnt), None, None, 0, dev, 2) == 0
+
+
+def test_resident_shards_entry_validates_before_it_starts_workers(bd):
+    """bd_analyze_batch_devices: missing arrays, bad kinds, lengths and strides are reported once, up front (no
+    pointer of a shard is touched); without a GPU a well-formed call says so instead of computing on the CPU."""
+    import ctypes as C
+    import torch
+    L = bd.lib()
+    vp, u64 = C.c_void_p, C.c_uint64
+    dev = (C.c_int * 2)(0, 0)
+    ptrs = (vp * 2)(0x1000, 0x2000)          # never dereferenced by the checks
+    n = (u64 * 2)(3, 4)
+    none = (vp * 2)(None, None)
+    call = lambda kind, samples, n_streams, n_samples, stride, cb, flags, count, devices, n_dev: L.bd_analyze_batch_devices(
+        kind, 44100, None, samples, n_streams, n_samples, stride, cb, None, flags, 0, count, None, None, 0, devices, n_dev)
+    assert call(1, ptrs, n, 2048, 2048, 512, ptrs, ptrs, None, 0) == -1        # no devices
+    assert call(1, None, n, 2048, 2048, 512, ptrs, ptrs, dev, 2) == -1         # no sample array
+    assert call(1, ptrs, None, 2048, 2048, 512, ptrs, ptrs, dev, 2) == -1      # no stream counts
+    assert call(1, ptrs, n, 2048, 2048, 512, None, ptrs, dev, 2) == -1         # no decision rows
+    assert call(1, ptrs, n, 2048, 2048, 512, ptrs, None, dev, 2) == -1         # no beat counts
+    assert call(7, ptrs, n, 2048, 2048, 512, ptrs, ptrs, dev, 2) == -1         # unknown strategy
+    assert call(1, ptrs, n, 2048, 2048, 0, ptrs, ptrs, dev, 2) == -5           # empty callbacks
+    assert call(1, ptrs, n, 2048, 1024, 512, ptrs, ptrs, dev, 2) == -1         # stride shorter than the stream
+    if not torch.cuda.is_available():
+        assert call(1, ptrs, n, 2048, 2048, 512, ptrs, ptrs, dev, 2) == -2     # BD_ERR_NO_DEVICE
+    else:
+        assert call(1, none, n, 2048, 2048, 512, ptrs, ptrs, dev, 2) == -1     # a shard without samples
+        bad = (C.c_int * 2)(0, 1 << 20)
+        assert call(1, ptrs, n, 2048, 2048, 512, ptrs, ptrs, bad, 2) == -1     # device out of range
