@@ -1,7 +1,8 @@
 """Seeded differential sweep: random callback lengths, stream counts and lengths, row strides and
 base offsets (rows that are only 2-byte aligned), both strategies and the documented parameter
 variants, each compared with the CPU oracle.  Exercises every kernel the length routing can pick
-(half-block, granule 64 / 32 / 16, window, generic, LPF aligned and line staging) on inputs no
+(half-block with one, two and four callbacks per half-block, granule 64 / 32 / 16, split, window, generic, LPF aligned and
+line staging) on inputs no
 hand-written case lists."""
 import os
 
@@ -24,7 +25,7 @@ def _case(rng):
     elif pick < 0.60:
         L = 16 * int(rng.integers(1, 40))
     elif pick < 0.75:
-        L = int(rng.choice([441, 480, 882, 960, 1323, 160, 320, 100, 1000]))
+        L = int(rng.choice([441, 480, 882, 960, 1323, 160, 320, 100, 1000, 128, 256, 529, 200]))
     else:
         L = int(rng.integers(1, 5000))
     n_streams = int(rng.integers(1, 6))
@@ -34,6 +35,8 @@ def _case(rng):
         n = L
     pad = int(rng.integers(0, 10))
     off = int(rng.integers(0, 8))
+    if rng.random() < 0.3:          # rows on 16-byte boundaries: the kernels with aligned loads
+        off, pad = 0, (-n) % 8
     sr = int(rng.choice([SR, SR, SR, 48000, 22050, 96000]))
     return kind_name, L, n_streams, n, pad, off, sr
 
