@@ -880,6 +880,16 @@ def test_tuning_knobs_do_not_change_results(bd, oracle, knobs):
         knobs.set("BD_LPF_VARIANT", variant)
         for L in (441, 65, 200, 1000):
             _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+    knobs.set("BD_LPF_VARIANT", "7")        # line staging for the lengths of the aligned staging as well
+    for L in (1024, 64, 4096, 136, 2048, 192):
+        _compare(bd, oracle, "LPF", SR, x, L, exact_values=True)
+        assert bd.last_kernel_name() == "bd_lpf_lines_kernel"
+    knobs.unset("BD_LPF_VARIANT")
+    knobs.set("BD_SPEC_NO_QUARTER", "1")    # 256- and 128-sample callbacks through the granule kernel
+    for L in (256, 128):
+        _compare(bd, oracle, "Spectrum", SR, x, L)
+        assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
+    knobs.unset("BD_SPEC_NO_QUARTER")
 
 
 def test_row_layouts(bd, oracle):
