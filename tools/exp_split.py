@@ -1,11 +1,11 @@
 """Rates of the Spectrum kernels for callback lengths around 400-640 (tools, not product).
-Environment: STREAMS, KIND (Spectrum | LPF), LENGTHS (comma separated), KNOB=<switch>:<v1>,<v2>,... sweeps one experiment switch of the
+Environment: STREAMS, KIND (Spectrum | LPF), SR, LENGTHS (comma separated), KNOB=<switch>:<v1>,<v2>,... sweeps one experiment switch of the
 library (for example KNOB=split_subruns:1,4,8) inside one process, so every value sees the same buffer."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import beat_detector_amd as bd
-SR = 44100
+SR = int(os.environ.get("SR", "44100"))     # sampling rate: decides how many bins the band holds
 KIND = bd.StrategyKind[os.environ.get("KIND", "Spectrum")]
 streams, n = int(os.environ.get("STREAMS", "2048")), SR * 60
 buf = torch.empty((streams, (n + 63) & ~63), dtype=torch.int16, device="cuda")
