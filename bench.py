@@ -67,6 +67,13 @@ WORKLOADS = {
     "spectrum_529": ("Spectrum", 529, 16384, 60,
                      "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, 529-sample callbacks "
                      "against the 1024-sample ring"),
+    # the usual low-latency buffer sizes: two and four callbacks per half-block of the same kernel
+    "spectrum_256": ("Spectrum", 256, 16384, 60,
+                     "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, 256-sample callbacks "
+                     "against the 1024-sample ring"),
+    "spectrum_128": ("Spectrum", 128, 16384, 60,
+                     "Spectrum strategy batched: 16,384 synthetic streams x 60 s @ 44.1 kHz, 128-sample callbacks "
+                     "against the 1024-sample ring"),
     "lpf_441": ("LPF", 441, 4096, 60,
                 "LPF strategy batched: 4,096 synthetic click-track streams x 60 s @ 44.1 kHz, 441-sample windows"),
     # extension analysis (no reference counterpart): callback_len is the hop
