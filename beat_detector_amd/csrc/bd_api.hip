@@ -109,6 +109,7 @@ static const bd_tuning *bd_tuning_read()
     t->spec_lds_pad = pad < 0 ? -1 : (pad > 140000 ? 140000 : (int)pad);
     t->spec_no_split = set("BD_SPEC_NO_SPLIT");
     t->spec_no_quarter = set("BD_SPEC_NO_QUARTER");
+    t->refractory_wave = set("BD_REFRACTORY_WAVE");
     t->spec_no_granule = set("BD_SPEC_NO_GRANULE");
     t->spec_no_small_granule = set("BD_SPEC_NO_SMALL_GRANULE");
     t->spec_depth = (int)num("BD_SPEC_DEPTH");

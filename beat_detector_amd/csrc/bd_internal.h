@@ -46,6 +46,7 @@ struct bd_tuning {
     int      spec_lds_pad;           // BD_SPEC_LDS_PAD: unused dynamic LDS, caps the half-block kernel's residency (-1 = default)
     int      spec_no_split;          // BD_SPEC_NO_SPLIT: no split kernel
     int      spec_no_quarter;        // BD_SPEC_NO_QUARTER: 256-sample callbacks through the granule kernel
+    int      refractory_wave;        // BD_REFRACTORY_WAVE: the refractory pass with a wavefront per stream for all rows
     int      spec_no_granule;        // BD_SPEC_NO_GRANULE: generic kernel for everything off the half-block path
     int      spec_no_small_granule;  // BD_SPEC_NO_SMALL_GRANULE: no granules below 64 samples
     int      spec_depth;             // BD_SPEC_DEPTH: register buffers of the half-block kernel (2, 3, 4; 0 = default)

@@ -550,14 +550,14 @@ def test_refractory_rule_dense_decisions(bd, oracle):
     import ctypes as C
     torch = _torch()
     rng = np.random.default_rng(5)
-    for sr, L in ((44100, 1024), (44100, 512), (48000, 480), (8000, 4000), (44100, 1), (96000, 20000)):
+    # the last two: a clock that wraps u32 within the batch (the launcher then leaves every decision to the rule itself)
+    for sr, L in ((44100, 1024), (44100, 512), (48000, 480), (8000, 4000), (44100, 1), (96000, 20000), (44100, 100),
+                  (44100, 300_000_000), (8000, 49_000_000)):
         n_cb = 700
         flags = np.stack([np.ones(n_cb, np.uint8), np.zeros(n_cb, np.uint8),
                           (rng.random(n_cb) < 0.3).astype(np.uint8), (rng.random(n_cb) < 0.02).astype(np.uint8)])
-        count, idx, ms = bd.refractory(sr, L, torch.from_numpy(flags).cuda(), max_beats=n_cb)
-        torch.cuda.synchronize()
-        count, idx, ms = count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()
         Lo = oracle.lib()
+        wants = []
         for s in range(flags.shape[0]):
             st = oracle.State()
             Lo.bdo_state_new(C.byref(st), sr)
@@ -567,43 +567,61 @@ def test_refractory_rule_dense_decisions(bd, oracle):
                 if Lo.bdo_last_beat_beyond_threshold(C.byref(st), 400) and flags[s, j]:
                     Lo.bdo_state_mark_beat(C.byref(st))
                     want.append((j, st.beat_time_ms))
-            got = list(zip(idx[s, :count[s]].tolist(), ms[s, :count[s]].tolist()))
-            assert got == want, (sr, L, s)
+            wants.append(want)
+        # rows of 700 bytes go a wavefront per stream; rows padded to 704 bytes a lane per stream
+        padded = torch.zeros((flags.shape[0], 704), dtype=torch.uint8, device="cuda")
+        padded[:, :n_cb] = torch.from_numpy(flags).cuda()
+        for rows in (torch.from_numpy(flags).cuda(), padded[:, :n_cb]):
+            count, idx, ms = bd.refractory(sr, L, rows, max_beats=n_cb)
+            torch.cuda.synchronize()
+            count, idx, ms = count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()
+            for s in range(flags.shape[0]):
+                got = list(zip(idx[s, :count[s]].tolist(), (ms[s, :count[s]].astype(np.int64) & 0xffffffff).tolist()))
+                assert got == wants[s], (sr, L, s, rows.stride(0))
 
 
-@pytest.mark.parametrize("n_cb", [1, 15, 16, 17, 1023, 1024, 1025, 1039, 2049, 5167])
+@pytest.mark.parametrize("n_cb", [1, 15, 16, 17, 31, 1023, 1024, 1025, 1039, 2049, 4095, 4096, 4097, 5119, 5120, 5167, 8192, 8193,
+                                  20671, 24576, 24577])
 def test_refractory_rows_on_16_byte_boundaries_and_any_nonzero_byte(bd, oracle, n_cb):
-    """Rows that start on 16-byte boundaries are read 1024 decisions at a time, the others 64 at a time;
-    a decision is any non-zero byte (0x01, 0x80, 0xff, ...); bytes between n_cb and the row stride are
-    not decisions."""
+    """The kernels of the refractory pass against the reference's clock and gate.  Rows on 16-byte boundaries of 16 to
+    24,576 callbacks: 8 streams per wavefront, packed to bits in segments of 4,096 callbacks, a lane per stream; other
+    rows: a wavefront per stream, 1,024 decisions per step on long rows on 16-byte boundaries, 64 otherwise.  13 streams
+    (a full wavefront of 8 and one of 5); a decision is any non-zero byte (0x01, 0x80, 0xff, ...); bytes between n_cb and
+    the row stride are not decisions."""
     import ctypes as C
     torch = _torch()
     rng = np.random.default_rng(n_cb)
     sr, L = 44100, 512
+    n_streams = 13
     stride = ((n_cb + 15) & ~15) + 16
-    host = rng.integers(1, 256, (6, stride)).astype(np.uint8)        # garbage past n_cb
-    dens = [1.0, 0.0, 0.5, 0.05, 0.01, 0.2]
-    for s in range(6):
+    host = rng.integers(1, 256, (n_streams, stride)).astype(np.uint8)        # garbage past n_cb
+    dens = [1.0, 0.0, 0.5, 0.05, 0.01, 0.2, 0.002, 0.1, 0.0005, 1.0, 0.03, 0.3, 0.007]
+    for s in range(n_streams):
         host[s, :n_cb] = np.where(rng.random(n_cb) < dens[s], rng.choice([1, 2, 0x80, 0xff], n_cb), 0)
-    for shift in (0, 3):                      # rows on and off 16-byte boundaries
+    Lo = oracle.lib()
+    wants = []
+    for s in range(n_streams):
+        st = oracle.State()
+        Lo.bdo_state_new(C.byref(st), sr)
+        want = []
+        for j in range(n_cb):
+            Lo.bdo_state_update_time(C.byref(st), L)
+            if host[s, j] and Lo.bdo_last_beat_beyond_threshold(C.byref(st), 400):
+                Lo.bdo_state_mark_beat(C.byref(st))
+                want.append((j, st.beat_time_ms))
+        wants.append(want)
+    # rows on 16-byte boundaries: the launcher's choice, and (switch) a wavefront per stream; rows off them: a wavefront per stream
+    for shift, wave in ((0, 0), (0, 1), (3, 0)):
         flat = torch.zeros(shift + host.size + 16, dtype=torch.uint8, device="cuda")
-        view = flat[shift:shift + host.size].view(6, stride)
+        view = flat[shift:shift + host.size].view(n_streams, stride)
         view.copy_(torch.from_numpy(host).cuda())
-        count, idx, ms = bd.refractory(sr, L, view[:, :n_cb], max_beats=n_cb)
-        torch.cuda.synchronize()
+        with bd.tuning(refractory_wave=wave or None):
+            count, idx, ms = bd.refractory(sr, L, view[:, :n_cb], max_beats=n_cb)
+            torch.cuda.synchronize()
         count, idx, ms = count.cpu().numpy(), idx.cpu().numpy(), ms.cpu().numpy()
-        Lo = oracle.lib()
-        for s in range(6):
-            st = oracle.State()
-            Lo.bdo_state_new(C.byref(st), sr)
-            want = []
-            for j in range(n_cb):
-                Lo.bdo_state_update_time(C.byref(st), L)
-                if Lo.bdo_last_beat_beyond_threshold(C.byref(st), 400) and host[s, j]:
-                    Lo.bdo_state_mark_beat(C.byref(st))
-                    want.append((j, st.beat_time_ms))
+        for s in range(n_streams):
             got = list(zip(idx[s, :count[s]].tolist(), ms[s, :count[s]].tolist()))
-            assert got == want, (n_cb, shift, s)
+            assert got == wants[s], (n_cb, shift, wave, s)
 
 
 def test_beat_list_capacity_is_reported_not_overrun(bd):
@@ -890,6 +908,10 @@ def test_tuning_knobs_do_not_change_results(bd, oracle, knobs):
         _compare(bd, oracle, "Spectrum", SR, x, L)
         assert bd.last_kernel_name() == "bd_spectrum_granule_kernel"
     knobs.unset("BD_SPEC_NO_QUARTER")
+    knobs.set("BD_REFRACTORY_WAVE", "1")    # the refractory pass with a wavefront per stream on every row
+    for kind_name, L in (("Spectrum", 512), ("LPF", 1024), ("Spectrum", 64), ("LPF", 16)):
+        _compare(bd, oracle, kind_name, SR, x, L, exact_values=(kind_name == "LPF"))
+    knobs.unset("BD_REFRACTORY_WAVE")
 
 
 def test_row_layouts(bd, oracle):
