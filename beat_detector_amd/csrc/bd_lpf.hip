@@ -447,10 +447,10 @@ int bd_launch_lpf(const bd_plan &plan, const int16_t *samples, uint64_t n_stream
     a.alpha = plan.alpha; a.ratio = plan.lpf_ratio;
     // Rows that keep their place inside a 128-byte line (callback length a multiple of 64) use the
     // aligned staging; so do short callbacks, where the partial first and last lines of the line
-    // staging weigh more than the lines it saves (4,096 x 60 s: 120 samples 5.9 vs 3.8 TB/s, 144: 4.7 vs 4.3,
-    // 160: 4.65 both, 176: 4.3 vs 4.8, 200: 4.3 vs 5.0, 248: 4.7 vs 5.4).
+    // staging weigh more than the lines it saves (8,192 x 60 s: 120 samples 5.9 vs 4.2 TB/s, 136: 4.5 vs 4.45,
+    // 144: 4.65 vs 4.6, 152: 4.45 vs 4.7, 160: 4.65 vs 5.0; from 168 samples on the two are level).
     const bool aligned = ((uintptr_t)samples % 16 == 0) && (stride % 8 == 0) && (callback_len % 8 == 0) &&
-                         (callback_len % 64 == 0 || callback_len <= 160) &&
+                         (callback_len % 64 == 0 || callback_len <= 144) &&
                          !(bd_tuning_get().lpf_variant == 7 && callback_len >= 64);   // 7: line staging wherever it applies
     // tuning knob for experiments: 0 = 128-sample chunks, 2 wavefronts per workgroup (default);
     // 1 = 128 / 1; 3 = 64-sample chunks, 4 wavefronts
